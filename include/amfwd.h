@@ -1,0 +1,157 @@
+/*
+ * amfwd.h -- C ABI of libamfwd.so: MI355X (gfx950) acoustic-model posterior engine.
+ *
+ * Drop-in boundary for the posterior-compute path of OrcusCZ/NNAcousticModeling.  The reference has no
+ * FFI of its own: the functions below replace, for that path only, what the reference does
+ * through Chainer/numpy calls.  Each entry point cites the reference code it stands in for (paths relative
+ * to the reference repo root).  Plain C types only; no framework types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative AM_E* code; am_last_error() gives a thread-local
+ *     message for the calling thread's last failure;
+ *   - all host arrays are caller-owned, row-major float32 unless stated; the library copies what it keeps;
+ *   - a handle (engine/model/pipeline) is bound to one device and is NOT re-entrant; different engines may be
+ *     driven from different host threads (one per GPU);
+ *   - there is no CPU fallback: without a usable gfx950 device am_engine_create() fails.
+ */
+#ifndef AMFWD_H
+#define AMFWD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AM_OK 0
+#define AM_EINVAL (-22)  /* bad argument / bad state          */
+#define AM_ENODEV (-19)  /* no usable GPU                     */
+#define AM_ENOMEM (-12)  /* host or device allocation failed  */
+#define AM_EHIP (-5)     /* a HIP runtime call failed         */
+
+typedef struct am_engine am_engine;     /* one device: stream, events, workspace            */
+typedef struct am_model am_model;       /* one network's weights, resident on the device    */
+typedef struct am_pipeline am_pipeline; /* frontend + member models + epilogue + I/O buffers */
+
+/* network kinds: chainer_networks.py:163-184 (get_nn) -- only the in-scope ones */
+enum { AM_NET_FF = 0, AM_NET_LSTM = 1 };
+/* FF activation: evaluate.py:96-103 / predict_folds.py:144-152 */
+enum { AM_ACT_RELU = 0, AM_ACT_SIGMOID = 1, AM_ACT_TANH = 2 };
+/* how member outputs are combined */
+enum {
+    AM_COMBINE_LOGITS = 0,   /* NNWithRPL.__call__, evaluate.py:35-51: raw-logit averaging          */
+    AM_COMBINE_LOGPOST = 1   /* predict_folds.py:199-220: mean of per-member log-posteriors, renormalised */
+};
+
+/* ---- discovery / errors ------------------------------------------------------------------------- */
+int am_device_count(void);            /* number of visible HIP devices, 0 if none (never negative) */
+const char* am_last_error(void);      /* thread-local, never NULL                                   */
+const char* am_version(void);
+
+/* ---- engine --------------------------------------------------------------------------------------- */
+/* replaces chainer.cuda.get_device_from_id(gpu).use() / model.to_gpu() (predict_folds.py:158-161,
+ * evaluateModelForTest.py:47-50).  Fails with AM_ENODEV when `device` is not a gfx950 GPU. */
+int am_engine_create(int device, am_engine** out);
+int am_engine_destroy(am_engine* e);
+int am_engine_synchronize(am_engine* e);
+int am_engine_device_name(am_engine* e, char* buf, int buflen);
+
+/* HIP events on the engine's compute stream (the stream every kernel below is launched on).
+ * slot in [0, 64).  Used by bench.py for the timed region. */
+int am_event_record(am_engine* e, int slot);
+int am_event_elapsed_ms(am_engine* e, int slot_start, int slot_stop, float* ms); /* synchronises on slot_stop */
+
+/* Per-kernel timing: when on, every kernel launch is bracketed by a HIP event pair on the compute stream.
+ * am_profile_read synchronises and returns, per kernel id, the number of launches and the summed duration
+ * since the last reset. */
+#define AM_KERNEL_ID_MAX 16
+int am_profile_enable(am_engine* e, int on);
+int am_profile_reset(am_engine* e);
+int am_profile_read(am_engine* e, int64_t calls[AM_KERNEL_ID_MAX], double ms[AM_KERNEL_ID_MAX]);
+const char* am_kernel_name(int kernel_id); /* NULL when out of range */
+
+/* ---- models --------------------------------------------------------------------------------------- */
+/* replaces get_nn + L.Classifier + serializers.load_npz (chainer_networks.py:163-184, evaluate.py:134-136,
+ * predict_folds.py:153-157,206).  Weights in Chainer layout:
+ *   AM_NET_FF  : n_layers hidden Linear + 1 output Linear -> (n_layers+1) entries of W[out,in], b[out];
+ *                W_lat must be NULL.
+ *   AM_NET_LSTM: n_layers L.LSTM + 1 output Linear.  For l < n_layers: W[l] = upward.W [4U,in],
+ *                b[l] = upward.b [4U], W_lat[l] = lateral.W [4U,U], gates interleaved (column 4u+k, k=a,i,f,o);
+ *                entry n_layers is the output Linear.  W_lat has n_layers entries.
+ * in_dims/out_dims have n_layers+1 entries (out_dims[l] = 4U for LSTM layers).  Layer input sizes must chain. */
+int am_model_create(am_engine* e, int kind, int n_layers, int activation,
+                    const int* in_dims, const int* out_dims,
+                    const float* const* W, const float* const* b, const float* const* W_lat,
+                    am_model** out);
+int am_model_destroy(am_model* m);
+
+/* ---- pipeline ------------------------------------------------------------------------------------- */
+int am_pipeline_create(am_engine* e, am_pipeline** out);
+int am_pipeline_destroy(am_pipeline* p);
+
+/* Fused splice + Kaldi feature transform (+ i-vector passthrough columns).
+ * replaces splicing (kw_utils.py:24-36) / prepareBatch (kw_nn_utils.py:19-43) +
+ * applyKaldiFeatureTransform (kw_nn_utils.py:13-17) + np.concatenate((data, ivectors)) (evaluate.py:169-171).
+ * shifts: n_shifts frame offsets (e.g. -5..5; {0} = no splice).  add_shift/rescale: [n_shifts*D] or both NULL
+ * (no transform).  d_iv: number of i-vector columns appended AFTER the transform (0 = none). */
+int am_pipeline_set_frontend(am_pipeline* p, int D, int n_shifts, const int* shifts,
+                             const float* add_shift, const float* rescale, int d_iv);
+
+/* Member networks and how they are combined.  All members must be of the same kind and output size.
+ * AM_COMBINE_LOGITS follows NNWithRPL (evaluate.py:35-51): has_master=1 -> members[0] is the master:
+ *   K=n-1 folds: K==0 -> master(x); else (K*master + sum folds)/(2K);  has_master=0 -> (sum folds)/n.
+ * AM_COMBINE_LOGPOST follows predict_folds.py:199-220 (has_master must be 0). */
+int am_pipeline_set_members(am_pipeline* p, int n_members, am_model* const* members, int has_master, int combine);
+
+/* RPL4 epilogue (RPL.py:58-74): W, b, lb each [C]; all NULL disables it. */
+int am_pipeline_set_rpl4(am_pipeline* p, const float* W, const float* b, const float* lb);
+
+/* Prior subtraction y - ap (evaluateModelForTest.py:75-76,110-111); ap [C] already scaled by --ap-coef
+ * (evaluate.py:174); NULL disables it (surface B, predict_folds). */
+int am_pipeline_set_prior(am_pipeline* p, const float* ap);
+
+/* Whether the final y - logsum(y) (kw_utils.py:38-43) is applied (default 1). 0 returns the combined logits. */
+int am_pipeline_set_normalise(am_pipeline* p, int on);
+
+/* ---- feed-forward path ---------------------------------------------------------------------------- */
+/* One contiguous frame shard.  x: [halo_lo + n + halo_hi, D] -- the shard's n frames plus the context rows
+ * that exist around it in the file; the splice clamps at the ends of THIS array, so pass halo = max|shift|
+ * unless the shard touches the start/end of the file (global clamp, kw_utils.py:29-33).
+ * ivec: [n, d_iv] or NULL.  am_ff_upload copies to HBM; am_ff_run launches the whole device path on the
+ * compute stream (asynchronous); am_ff_download copies y [n, C] back and synchronises.
+ * am_forward_ff = the three in sequence.  Replaces the FF branch of predict (predict_folds.py:69-94) and of
+ * evaluateModelTestTri (evaluateModelForTest.py:98-112). */
+int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, int64_t n, int halo_lo, int halo_hi);
+int am_ff_run(am_pipeline* p);
+int am_ff_download(am_pipeline* p, float* y);
+int am_forward_ff(am_pipeline* p, const float* x, const float* ivec, int64_t n, int halo_lo, int halo_hi, float* y);
+
+/* ---- recurrent path ------------------------------------------------------------------------------- */
+/* x: [N, D] frames of n_utts whole utterances, offsets: [n_utts+1] (offsets[0]=0, offsets[n_utts]=N).
+ * timedelay >= 0: output frame j of an utterance is the network output at step j + timedelay
+ * (predict_folds.py:59-61).  The reference edge-pads each utterance by `timedelay` rows (predict_folds.py:39) but
+ * stores a step only for utterances whose un-padded length exceeds t (predict_folds.py:50,61), so the last
+ * `timedelay` output frames of every utterance are exactly 0 -- reproduced here.  Pass 0 for the evaluate
+ * behaviour (evaluateModelForTest.py:67-80).  y: [N, C] in file order. */
+int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec, const int64_t* offsets, int n_utts, int timedelay);
+int am_lstm_run(am_pipeline* p);
+int am_lstm_download(am_pipeline* p, float* y);
+int am_forward_lstm(am_pipeline* p, const float* x, const float* ivec, const int64_t* offsets, int n_utts,
+                    int timedelay, float* y);
+
+/* number of frames / classes of the resident output (after *_upload) */
+int am_pipeline_output_shape(am_pipeline* p, int64_t* n, int* c);
+
+/* ---- stand-alone stage entry points (parity tests + roofline measurements) ------------------------ */
+/* splice+transform only: out [n, n_shifts*D + d_iv] (host). */
+int am_frontend_apply(am_pipeline* p, const float* x, const float* ivec, int64_t n, int halo_lo, int halo_hi, float* out);
+/* y - logsum(y) in place on host data through the device kernel (a14), with optional prior. lp: [n, c]. */
+int am_lognormalise(am_engine* e, float* lp, int64_t n, int c, const float* ap);
+/* single Linear (+activation) through the MFMA GEMM kernel: y[n,out] = act(x[n,in] W[out,in]^T + b); act<0 = none. */
+int am_linear(am_engine* e, const float* x, int64_t n, int in_dim, const float* W, const float* b, int out_dim,
+              int act, float* y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMFWD_H */

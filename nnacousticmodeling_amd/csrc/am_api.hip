@@ -1,0 +1,868 @@
+// C-ABI host layer of libamfwd.so (see include/amfwd.h).  Owns device memory, streams and the launch sequence;
+// every arithmetic step runs in the gfx950 kernels of am_kernels.hip.  There is no CPU fallback.
+#include "../../include/amfwd.h"
+#include "am_internal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+using namespace am;
+
+// ----------------------------------------------------------------------------------------------------
+// errors
+// ----------------------------------------------------------------------------------------------------
+static thread_local std::string g_err = "";
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(_e == hipErrorOutOfMemory ? AM_ENOMEM : AM_EHIP, "%s failed: %s (%s:%d)", #expr, \
+                        hipGetErrorString(_e), __FILE__, __LINE__);                                \
+    } while (0)
+
+#define AM_TRY(expr)            \
+    do {                        \
+        int _r = (expr);        \
+        if (_r != AM_OK) return _r; \
+    } while (0)
+
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// ----------------------------------------------------------------------------------------------------
+// objects
+// ----------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return AM_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        HIP_TRY(hipMalloc(&p, bytes));
+        cap = bytes;
+        return AM_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct am_engine {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[64] = {};
+    bool profile = false;
+    struct Rec { int id; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    int64_t prof_calls[AM_KERNEL_ID_MAX] = {};
+    double prof_ms[AM_KERNEL_ID_MAX] = {};
+    char name[256] = {};
+    DevBuf scratch[4];  // stand-alone stage entry points
+};
+
+struct Layer {
+    int in = 0, out = 0, in_pad = 0, out_pad = 0;
+    int U = 0, U_pad = 0;  // LSTM layers only
+    DevBuf W, b, Wlat;
+};
+
+struct am_model {
+    am_engine* e = nullptr;
+    int kind = 0, n_layers = 0, act = 0;
+    std::vector<Layer> L;  // n_layers + 1 (last = output Linear)
+    int in_dim = 0, in_pad = 0, C = 0, C_pad = 0;
+    int max_width = 0;     // widest padded hidden activation
+};
+
+struct am_pipeline {
+    am_engine* e = nullptr;
+    // frontend
+    int D = 0, n_shifts = 0, d_iv = 0;
+    bool has_ft = false;
+    DevBuf d_shifts, d_add, d_scale;
+    // members
+    std::vector<am_model*> members;
+    int has_master = 0, combine = AM_COMBINE_LOGITS;
+    // epilogue
+    bool has_rpl = false, has_prior = false;
+    DevBuf d_rplw, d_rplb, d_rpllb, d_prior;
+    int normalise = 1;
+    // resident state
+    int mode = 0;  // 0 nothing uploaded, 1 ff, 2 lstm
+    int64_t n = 0;
+    int halo_lo = 0, halo_hi = 0;
+    bool has_ivec = false;
+    DevBuf d_x, d_ivec, d_in, d_act0, d_act1, d_acc, d_acc2, d_out;
+    // lstm
+    DevBuf d_src, d_dst, d_G, d_H0, d_H1, d_c;
+    std::vector<int64_t> step_off;
+    std::vector<int> n_active;
+    int64_t n_packed = 0;
+    int n_slots = 0;
+};
+
+static constexpr int64_t FF_CHUNK_ROWS = 1 << 18;
+
+// ----------------------------------------------------------------------------------------------------
+// kernel launch with optional event bracketing
+// ----------------------------------------------------------------------------------------------------
+template <class F>
+static int run_kernel(am_engine* e, int id, F&& launch)
+{
+    hipEvent_t a = nullptr, b = nullptr;
+    if (e->profile) {
+        for (hipEvent_t* ev : {&a, &b}) {
+            if (!e->pool.empty()) { *ev = e->pool.back(); e->pool.pop_back(); }
+            else HIP_TRY(hipEventCreate(ev));
+        }
+        HIP_TRY(hipEventRecord(a, e->stream));
+    }
+    hipError_t r = launch();
+    if (r != hipSuccess) return fail(AM_EHIP, "launch of %s failed: %s", am_kernel_name(id), hipGetErrorString(r));
+    if (e->profile) {
+        HIP_TRY(hipEventRecord(b, e->stream));
+        e->recs.push_back({id, a, b});
+    }
+    return AM_OK;
+}
+
+static int drain_profile(am_engine* e)
+{
+    if (e->recs.empty()) return AM_OK;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (auto& r : e->recs) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        e->prof_calls[r.id] += 1;
+        e->prof_ms[r.id] += ms;
+        e->pool.push_back(r.a);
+        e->pool.push_back(r.b);
+    }
+    e->recs.clear();
+    return AM_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// discovery / engine
+// ----------------------------------------------------------------------------------------------------
+extern "C" int am_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+extern "C" const char* am_last_error(void) { return g_err.c_str(); }
+extern "C" const char* am_version(void) { return "amfwd 0.1 (gfx950)"; }
+
+extern "C" const char* am_kernel_name(int id)
+{
+    static const char* names[K_COUNT] = {"splice_ft", "gemm_hidden", "gemm_out", "finish", "gather_ft", "lstm_upward", "lstm_step"};
+    return (id >= 0 && id < K_COUNT) ? names[id] : nullptr;
+}
+
+extern "C" int am_engine_create(int device, am_engine** out)
+{
+    if (!out) return fail(AM_EINVAL, "am_engine_create: out is NULL");
+    *out = nullptr;
+    int n = am_device_count();
+    if (n <= 0) return fail(AM_ENODEV, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(AM_ENODEV, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(AM_ENODEV, "device %d is %s; libamfwd is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    am_engine* e = new am_engine();
+    e->device = device;
+    snprintf(e->name, sizeof(e->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(AM_EHIP, "hipStreamCreate failed"); }
+    hipError_t r = init_kernels();
+    if (r != hipSuccess) { (void)hipStreamDestroy(e->stream); delete e; return fail(AM_EHIP, "kernel init failed: %s", hipGetErrorString(r)); }
+    *out = e;
+    return AM_OK;
+}
+
+extern "C" int am_engine_destroy(am_engine* e)
+{
+    if (!e) return AM_OK;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    for (auto& r : e->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto ev : e->pool) (void)hipEventDestroy(ev);
+    for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& s : e->scratch) s.release();
+    (void)hipStreamDestroy(e->stream);
+    delete e;
+    return AM_OK;
+}
+
+extern "C" int am_engine_synchronize(am_engine* e)
+{
+    if (!e) return fail(AM_EINVAL, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return AM_OK;
+}
+
+extern "C" int am_engine_device_name(am_engine* e, char* buf, int buflen)
+{
+    if (!e || !buf || buflen <= 0) return fail(AM_EINVAL, "bad argument");
+    snprintf(buf, buflen, "%s", e->name);
+    return AM_OK;
+}
+
+extern "C" int am_event_record(am_engine* e, int slot)
+{
+    if (!e || slot < 0 || slot >= 64) return fail(AM_EINVAL, "bad event slot");
+    HIP_TRY(hipSetDevice(e->device));
+    if (!e->ev[slot]) HIP_TRY(hipEventCreate(&e->ev[slot]));
+    HIP_TRY(hipEventRecord(e->ev[slot], e->stream));
+    return AM_OK;
+}
+
+extern "C" int am_event_elapsed_ms(am_engine* e, int a, int b, float* ms)
+{
+    if (!e || !ms || a < 0 || a >= 64 || b < 0 || b >= 64 || !e->ev[a] || !e->ev[b]) return fail(AM_EINVAL, "bad event slot");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventSynchronize(e->ev[b]));
+    HIP_TRY(hipEventElapsedTime(ms, e->ev[a], e->ev[b]));
+    return AM_OK;
+}
+
+extern "C" int am_profile_enable(am_engine* e, int on)
+{
+    if (!e) return fail(AM_EINVAL, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    AM_TRY(drain_profile(e));
+    e->profile = on != 0;
+    return AM_OK;
+}
+
+extern "C" int am_profile_reset(am_engine* e)
+{
+    if (!e) return fail(AM_EINVAL, "engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    AM_TRY(drain_profile(e));
+    memset(e->prof_calls, 0, sizeof(e->prof_calls));
+    memset(e->prof_ms, 0, sizeof(e->prof_ms));
+    return AM_OK;
+}
+
+extern "C" int am_profile_read(am_engine* e, int64_t calls[AM_KERNEL_ID_MAX], double ms[AM_KERNEL_ID_MAX])
+{
+    if (!e || !calls || !ms) return fail(AM_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(e->device));
+    AM_TRY(drain_profile(e));
+    memcpy(calls, e->prof_calls, sizeof(e->prof_calls));
+    memcpy(ms, e->prof_ms, sizeof(e->prof_ms));
+    return AM_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// models
+// ----------------------------------------------------------------------------------------------------
+// All copies and memsets are stream-ordered on the engine's compute stream (a non-blocking stream does not
+// synchronise with the null stream), followed by a stream synchronise where the host buffer must be reusable.
+static int upload(am_engine* e, DevBuf& d, const std::vector<float>& h)
+{
+    AM_TRY(d.ensure(h.size() * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return AM_OK;
+}
+
+// destination row of (unit u, gate k) in the gate-tiled layout used by lstm_step_kernel
+static inline int gate_tiled_row(int u, int k) { return (u / 16) * 64 + k * 16 + (u % 16); }
+
+extern "C" int am_model_create(am_engine* e, int kind, int n_layers, int activation, const int* in_dims, const int* out_dims,
+                               const float* const* W, const float* const* b, const float* const* W_lat, am_model** out)
+{
+    if (!out) return fail(AM_EINVAL, "am_model_create: out is NULL");
+    *out = nullptr;
+    if (!e || !in_dims || !out_dims || !W || !b) return fail(AM_EINVAL, "am_model_create: NULL argument");
+    if (kind != AM_NET_FF && kind != AM_NET_LSTM) return fail(AM_EINVAL, "am_model_create: unknown network kind %d", kind);
+    if (n_layers < 0 || n_layers > 64) return fail(AM_EINVAL, "am_model_create: bad layer count %d", n_layers);
+    if (kind == AM_NET_FF && (activation < AM_ACT_RELU || activation > AM_ACT_TANH)) return fail(AM_EINVAL, "Wrong activation function specified");
+    if (kind == AM_NET_LSTM && (!W_lat || n_layers < 1)) return fail(AM_EINVAL, "am_model_create: LSTM needs lateral weights and >= 1 layer");
+    for (int l = 0; l <= n_layers; ++l) {
+        if (!W[l] || !b[l] || in_dims[l] <= 0 || out_dims[l] <= 0) return fail(AM_EINVAL, "am_model_create: layer %d has a NULL/empty parameter", l);
+        if (kind == AM_NET_LSTM && l < n_layers && (out_dims[l] % 4 != 0 || !W_lat[l])) return fail(AM_EINVAL, "am_model_create: LSTM layer %d malformed", l);
+        if (l > 0) {
+            const int prev = (kind == AM_NET_LSTM) ? out_dims[l - 1] / 4 : out_dims[l - 1];
+            if (in_dims[l] != prev) return fail(AM_EINVAL, "am_model_create: layer %d expects %d inputs but layer %d produces %d", l, in_dims[l], l - 1, prev);
+        }
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    am_model* m = new am_model();
+    m->e = e; m->kind = kind; m->n_layers = n_layers; m->act = activation;
+    m->L.resize(n_layers + 1);
+    m->in_dim = in_dims[0];
+    m->in_pad = (int)round_up(in_dims[0], GEMM_BK);
+    m->C = out_dims[n_layers];
+    m->C_pad = (int)round_up(m->C, GEMM_BN);
+    int rc = AM_OK;
+    for (int l = 0; l <= n_layers && rc == AM_OK; ++l) {
+        Layer& Ly = m->L[l];
+        Ly.in = in_dims[l]; Ly.out = out_dims[l];
+        const bool lstm_layer = (kind == AM_NET_LSTM && l < n_layers);
+        if (l == 0) Ly.in_pad = m->in_pad;
+        else Ly.in_pad = (kind == AM_NET_LSTM) ? m->L[l - 1].U_pad : m->L[l - 1].out_pad;
+        if (lstm_layer) {
+            Ly.U = Ly.out / 4;
+            Ly.U_pad = (int)round_up(Ly.U, 32);
+            Ly.out_pad = 4 * Ly.U_pad;
+            std::vector<float> w((size_t)Ly.out_pad * Ly.in_pad, 0.f), bb(Ly.out_pad, 0.f), wl((size_t)Ly.out_pad * Ly.U_pad, 0.f);
+            for (int u = 0; u < Ly.U; ++u)
+                for (int k = 0; k < 4; ++k) {
+                    const int src = 4 * u + k, dst = gate_tiled_row(u, k);
+                    memcpy(&w[(size_t)dst * Ly.in_pad], W[l] + (size_t)src * Ly.in, sizeof(float) * Ly.in);
+                    bb[dst] = b[l][src];
+                    memcpy(&wl[(size_t)dst * Ly.U_pad], W_lat[l] + (size_t)src * Ly.U, sizeof(float) * Ly.U);
+                }
+            if ((rc = upload(e, Ly.W, w)) != AM_OK) break;
+            if ((rc = upload(e, Ly.b, bb)) != AM_OK) break;
+            if ((rc = upload(e, Ly.Wlat, wl)) != AM_OK) break;
+            m->max_width = std::max(m->max_width, Ly.U_pad);
+        } else {
+            Ly.out_pad = (int)round_up(Ly.out, GEMM_BN);
+            std::vector<float> w((size_t)Ly.out_pad * Ly.in_pad, 0.f), bb(Ly.out_pad, 0.f);
+            for (int o = 0; o < Ly.out; ++o) memcpy(&w[(size_t)o * Ly.in_pad], W[l] + (size_t)o * Ly.in, sizeof(float) * Ly.in);
+            memcpy(bb.data(), b[l], sizeof(float) * Ly.out);
+            if ((rc = upload(e, Ly.W, w)) != AM_OK) break;
+            if ((rc = upload(e, Ly.b, bb)) != AM_OK) break;
+            if (l < n_layers) m->max_width = std::max(m->max_width, Ly.out_pad);
+        }
+    }
+    if (rc != AM_OK) { am_model_destroy(m); return rc; }
+    *out = m;
+    return AM_OK;
+}
+
+extern "C" int am_model_destroy(am_model* m)
+{
+    if (!m) return AM_OK;
+    (void)hipSetDevice(m->e->device);
+    for (auto& l : m->L) { l.W.release(); l.b.release(); l.Wlat.release(); }
+    delete m;
+    return AM_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// pipeline configuration
+// ----------------------------------------------------------------------------------------------------
+extern "C" int am_pipeline_create(am_engine* e, am_pipeline** out)
+{
+    if (!e || !out) return fail(AM_EINVAL, "am_pipeline_create: NULL argument");
+    am_pipeline* p = new am_pipeline();
+    p->e = e;
+    *out = p;
+    return AM_OK;
+}
+
+extern "C" int am_pipeline_destroy(am_pipeline* p)
+{
+    if (!p) return AM_OK;
+    (void)hipSetDevice(p->e->device);
+    (void)hipStreamSynchronize(p->e->stream);
+    for (DevBuf* d : {&p->d_shifts, &p->d_add, &p->d_scale, &p->d_rplw, &p->d_rplb, &p->d_rpllb, &p->d_prior, &p->d_x, &p->d_ivec, &p->d_in,
+                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_src, &p->d_dst, &p->d_G, &p->d_H0, &p->d_H1, &p->d_c})
+        d->release();
+    delete p;
+    return AM_OK;
+}
+
+extern "C" int am_pipeline_set_frontend(am_pipeline* p, int D, int n_shifts, const int* shifts, const float* add_shift, const float* rescale, int d_iv)
+{
+    if (!p || D <= 0 || n_shifts <= 0 || !shifts || d_iv < 0) return fail(AM_EINVAL, "am_pipeline_set_frontend: bad argument");
+    if ((add_shift == nullptr) != (rescale == nullptr)) return fail(AM_EINVAL, "am_pipeline_set_frontend: add_shift and rescale must both be given or both NULL");
+    HIP_TRY(hipSetDevice(p->e->device));
+    HIP_TRY(hipStreamSynchronize(p->e->stream));
+    p->D = D; p->n_shifts = n_shifts; p->d_iv = d_iv; p->has_ft = add_shift != nullptr;
+    AM_TRY(p->d_shifts.ensure(sizeof(int) * n_shifts));
+    HIP_TRY(hipMemcpyAsync(p->d_shifts.p, shifts, sizeof(int) * n_shifts, hipMemcpyHostToDevice, p->e->stream));
+    if (p->has_ft) {
+        const size_t bytes = sizeof(float) * (size_t)n_shifts * D;
+        AM_TRY(p->d_add.ensure(bytes));
+        AM_TRY(p->d_scale.ensure(bytes));
+        HIP_TRY(hipMemcpyAsync(p->d_add.p, add_shift, bytes, hipMemcpyHostToDevice, p->e->stream));
+        HIP_TRY(hipMemcpyAsync(p->d_scale.p, rescale, bytes, hipMemcpyHostToDevice, p->e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(p->e->stream));
+    p->mode = 0;
+    return AM_OK;
+}
+
+extern "C" int am_pipeline_set_members(am_pipeline* p, int n_members, am_model* const* members, int has_master, int combine)
+{
+    if (!p || n_members <= 0 || !members) return fail(AM_EINVAL, "am_pipeline_set_members: bad argument");
+    if (combine != AM_COMBINE_LOGITS && combine != AM_COMBINE_LOGPOST) return fail(AM_EINVAL, "am_pipeline_set_members: unknown combine mode");
+    if (combine == AM_COMBINE_LOGPOST && has_master) return fail(AM_EINVAL, "am_pipeline_set_members: log-posterior averaging has no master");
+    for (int i = 0; i < n_members; ++i) {
+        if (!members[i] || members[i]->e != p->e) return fail(AM_EINVAL, "am_pipeline_set_members: member %d is NULL or lives on another engine", i);
+        if (members[i]->kind != members[0]->kind || members[i]->C != members[0]->C || members[i]->in_dim != members[0]->in_dim)
+            return fail(AM_EINVAL, "am_pipeline_set_members: member %d differs in kind / input / output size", i);
+    }
+    if (members[0]->C > 2048) return fail(AM_EINVAL, "am_pipeline_set_members: at most 2048 classes are supported");
+    p->members.assign(members, members + n_members);
+    p->has_master = has_master ? 1 : 0;
+    p->combine = combine;
+    p->mode = 0;
+    return AM_OK;
+}
+
+static int set_vec(am_pipeline* p, DevBuf& d, const float* src, int c)
+{
+    AM_TRY(d.ensure(sizeof(float) * c));
+    HIP_TRY(hipMemcpyAsync(d.p, src, sizeof(float) * c, hipMemcpyHostToDevice, p->e->stream));
+    HIP_TRY(hipStreamSynchronize(p->e->stream));
+    return AM_OK;
+}
+
+extern "C" int am_pipeline_set_rpl4(am_pipeline* p, const float* W, const float* b, const float* lb)
+{
+    if (!p) return fail(AM_EINVAL, "pipeline is NULL");
+    if (!W && !b && !lb) { p->has_rpl = false; return AM_OK; }
+    if (!W || !b || !lb) return fail(AM_EINVAL, "am_pipeline_set_rpl4: W, b, lb must all be given");
+    if (p->members.empty()) return fail(AM_EINVAL, "am_pipeline_set_rpl4: set the members first");
+    HIP_TRY(hipSetDevice(p->e->device));
+    HIP_TRY(hipStreamSynchronize(p->e->stream));
+    const int c = p->members[0]->C;
+    AM_TRY(set_vec(p, p->d_rplw, W, c));
+    AM_TRY(set_vec(p, p->d_rplb, b, c));
+    AM_TRY(set_vec(p, p->d_rpllb, lb, c));
+    p->has_rpl = true;
+    return AM_OK;
+}
+
+extern "C" int am_pipeline_set_prior(am_pipeline* p, const float* ap)
+{
+    if (!p) return fail(AM_EINVAL, "pipeline is NULL");
+    if (!ap) { p->has_prior = false; return AM_OK; }
+    if (p->members.empty()) return fail(AM_EINVAL, "am_pipeline_set_prior: set the members first");
+    HIP_TRY(hipSetDevice(p->e->device));
+    HIP_TRY(hipStreamSynchronize(p->e->stream));
+    AM_TRY(set_vec(p, p->d_prior, ap, p->members[0]->C));
+    p->has_prior = true;
+    return AM_OK;
+}
+
+extern "C" int am_pipeline_set_normalise(am_pipeline* p, int on)
+{
+    if (!p) return fail(AM_EINVAL, "pipeline is NULL");
+    p->normalise = on ? 1 : 0;
+    return AM_OK;
+}
+
+static int check_ready(am_pipeline* p, int kind)
+{
+    if (!p) return fail(AM_EINVAL, "pipeline is NULL");
+    if (p->D <= 0) return fail(AM_EINVAL, "pipeline has no frontend (am_pipeline_set_frontend)");
+    if (p->members.empty()) return fail(AM_EINVAL, "pipeline has no member network (am_pipeline_set_members)");
+    if (p->members[0]->kind != kind) return fail(AM_EINVAL, "pipeline members are %s networks", p->members[0]->kind == AM_NET_FF ? "feed-forward" : "recurrent");
+    const int width = p->n_shifts * p->D + p->d_iv;
+    if (width != p->members[0]->in_dim)
+        return fail(AM_EINVAL, "frontend produces %d features per frame but the network expects %d", width, p->members[0]->in_dim);
+    return AM_OK;
+}
+
+// combine / finish shared by both paths ----------------------------------------------------------------
+static int epilogue_mode(const am_pipeline* p, int mi, float* alpha)
+{
+    *alpha = 1.f;
+    if (p->combine == AM_COMBINE_LOGPOST) return EPI_LINEAR;
+    const int n = (int)p->members.size();
+    if (mi > 0) return EPI_ACCUM;
+    if (p->has_master && n > 1) { *alpha = (float)(n - 1); return EPI_SCALE; }
+    return EPI_LINEAR;
+}
+
+static float final_divisor(const am_pipeline* p)
+{
+    const int n = (int)p->members.size();
+    if (p->combine == AM_COMBINE_LOGPOST) return (float)n;
+    if (p->has_master) return n > 1 ? 2.f * (n - 1) : 0.f;
+    return n > 1 ? (float)n : 0.f;
+}
+
+static int member_finish(am_pipeline* p, int mi, int64_t rows)
+{
+    // log-posterior averaging: normalise this member and add it to the running sum (predict_folds.py:207-212)
+    am_model* m0 = p->members[0];
+    FinishArgs f{};
+    f.in = p->d_acc.as<float>(); f.ldin = m0->C_pad;
+    f.out = p->d_acc2.as<float>(); f.ldout = m0->C_pad;
+    f.n = rows; f.C = m0->C; f.normalise = 1; f.accumulate = mi > 0;
+    return run_kernel(p->e, K_FINISH, [&] { return launch_finish(p->e->stream, f); });
+}
+
+static int final_finish(am_pipeline* p, int64_t rows, float* out, const int* row_map)
+{
+    am_model* m0 = p->members[0];
+    FinishArgs f{};
+    f.in = (p->combine == AM_COMBINE_LOGPOST ? p->d_acc2 : p->d_acc).as<float>(); f.ldin = m0->C_pad;
+    f.out = out; f.ldout = m0->C; f.row_map = row_map;
+    f.n = rows; f.C = m0->C;
+    f.divisor = final_divisor(p);
+    if (p->has_rpl) { f.rpl_w = p->d_rplw.as<float>(); f.rpl_b = p->d_rplb.as<float>(); f.rpl_lb = p->d_rpllb.as<float>(); }
+    if (p->has_prior) f.prior = p->d_prior.as<float>();
+    f.normalise = p->normalise;
+    return run_kernel(p->e, K_FINISH, [&] { return launch_finish(p->e->stream, f); });
+}
+
+// ----------------------------------------------------------------------------------------------------
+// feed-forward path
+// ----------------------------------------------------------------------------------------------------
+extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, int64_t n, int halo_lo, int halo_hi)
+{
+    AM_TRY(check_ready(p, AM_NET_FF));
+    if (!x || n < 0 || halo_lo < 0 || halo_hi < 0) return fail(AM_EINVAL, "am_ff_upload: bad argument");
+    if ((p->d_iv > 0) != (ivec != nullptr)) return fail(AM_EINVAL, "am_ff_upload: i-vectors %s", p->d_iv > 0 ? "expected but NULL" : "given but the frontend has d_iv = 0");
+    am_engine* e = p->e;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    am_model* m0 = p->members[0];
+    const int64_t ext = halo_lo + n + halo_hi;
+    if (n > 0 && ext <= 0) return fail(AM_EINVAL, "am_ff_upload: empty input");
+    const int64_t rows = std::min<int64_t>(round_up(std::max<int64_t>(n, 1), GEMM_BM), FF_CHUNK_ROWS);
+    int width = 0;
+    for (auto* m : p->members) width = std::max(width, m->max_width);
+    AM_TRY(p->d_x.ensure(std::max<size_t>(sizeof(float) * ext * p->D, 16)));
+    if (ext > 0) HIP_TRY(hipMemcpyAsync(p->d_x.p, x, sizeof(float) * ext * p->D, hipMemcpyHostToDevice, e->stream));
+    if (ivec) {
+        AM_TRY(p->d_ivec.ensure(std::max<size_t>(sizeof(float) * n * p->d_iv, 16)));
+        if (n > 0) HIP_TRY(hipMemcpyAsync(p->d_ivec.p, ivec, sizeof(float) * n * p->d_iv, hipMemcpyHostToDevice, e->stream));
+    }
+    AM_TRY(p->d_in.ensure(sizeof(float) * rows * m0->in_pad));
+    if (width > 0) {
+        AM_TRY(p->d_act0.ensure(sizeof(float) * rows * width));
+        AM_TRY(p->d_act1.ensure(sizeof(float) * rows * width));
+    }
+    AM_TRY(p->d_acc.ensure(sizeof(float) * rows * m0->C_pad));
+    if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(p->d_acc2.ensure(sizeof(float) * rows * m0->C_pad));
+    AM_TRY(p->d_out.ensure(std::max<size_t>(sizeof(float) * n * m0->C, 16)));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    p->n = n; p->halo_lo = halo_lo; p->halo_hi = halo_hi; p->has_ivec = ivec != nullptr;
+    p->mode = 1;
+    return AM_OK;
+}
+
+static int ff_member_forward(am_pipeline* p, int mi, int64_t rows_pad)
+{
+    am_engine* e = p->e;
+    am_model* m = p->members[mi];
+    const float* A = p->d_in.as<float>();
+    int lda = m->in_pad;
+    for (int l = 0; l <= m->n_layers; ++l) {
+        Layer& Ly = m->L[l];
+        GemmArgs g{};
+        g.A = A; g.lda = lda; g.W = Ly.W.as<float>(); g.ldw = Ly.in_pad; g.bias = Ly.b.as<float>();
+        g.M_pad = (int)rows_pad; g.N_pad = Ly.out_pad; g.K_pad = Ly.in_pad; g.act = m->act;
+        int id;
+        if (l < m->n_layers) {
+            g.C = ((l & 1) ? p->d_act1 : p->d_act0).as<float>(); g.ldc = Ly.out_pad; g.epi = EPI_ACT; g.alpha = 1.f;
+            id = K_GEMM_HIDDEN;
+        } else {
+            g.C = p->d_acc.as<float>(); g.ldc = m->C_pad; g.epi = epilogue_mode(p, mi, &g.alpha);
+            id = K_GEMM_OUT;
+        }
+        AM_TRY(run_kernel(e, id, [&] { return launch_gemm(e->stream, g); }));
+        A = g.C; lda = g.ldc;
+    }
+    return AM_OK;
+}
+
+extern "C" int am_ff_run(am_pipeline* p)
+{
+    if (!p || p->mode != 1) return fail(AM_EINVAL, "am_ff_run: nothing uploaded (am_ff_upload)");
+    am_engine* e = p->e;
+    HIP_TRY(hipSetDevice(e->device));
+    am_model* m0 = p->members[0];
+    for (int64_t c0 = 0; c0 < p->n; c0 += FF_CHUNK_ROWS) {
+        const int64_t nc = std::min<int64_t>(FF_CHUNK_ROWS, p->n - c0);
+        const int64_t nc_pad = round_up(nc, GEMM_BM);
+        SpliceArgs s{};
+        s.x = p->d_x.as<float>(); s.ext_rows = p->halo_lo + p->n + p->halo_hi; s.first = p->halo_lo + c0;
+        s.ivec = p->has_ivec ? p->d_ivec.as<float>() : nullptr; s.row0 = c0; s.n = nc; s.n_pad = nc_pad;
+        s.D = p->D; s.n_shifts = p->n_shifts; s.shifts = p->d_shifts.as<int>();
+        s.add = p->has_ft ? p->d_add.as<float>() : nullptr; s.scale = p->has_ft ? p->d_scale.as<float>() : nullptr;
+        s.d_iv = p->d_iv; s.out = p->d_in.as<float>(); s.ldo = m0->in_pad;
+        AM_TRY(run_kernel(e, K_SPLICE_FT, [&] { return launch_splice_ft(e->stream, s); }));
+        for (int mi = 0; mi < (int)p->members.size(); ++mi) {
+            AM_TRY(ff_member_forward(p, mi, nc_pad));
+            if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(member_finish(p, mi, nc));
+        }
+        AM_TRY(final_finish(p, nc, p->d_out.as<float>() + c0 * m0->C, nullptr));
+    }
+    return AM_OK;
+}
+
+extern "C" int am_ff_download(am_pipeline* p, float* y)
+{
+    if (!p || p->mode != 1 || !y) return fail(AM_EINVAL, "am_ff_download: nothing to download");
+    am_engine* e = p->e;
+    HIP_TRY(hipSetDevice(e->device));
+    if (p->n > 0) HIP_TRY(hipMemcpyAsync(y, p->d_out.p, sizeof(float) * p->n * p->members[0]->C, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return AM_OK;
+}
+
+extern "C" int am_forward_ff(am_pipeline* p, const float* x, const float* ivec, int64_t n, int halo_lo, int halo_hi, float* y)
+{
+    AM_TRY(am_ff_upload(p, x, ivec, n, halo_lo, halo_hi));
+    AM_TRY(am_ff_run(p));
+    return am_ff_download(p, y);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// recurrent path
+// ----------------------------------------------------------------------------------------------------
+extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec, const int64_t* offsets, int n_utts, int timedelay)
+{
+    AM_TRY(check_ready(p, AM_NET_LSTM));
+    if (!x || !offsets || n_utts < 0 || timedelay < 0) return fail(AM_EINVAL, "am_lstm_upload: bad argument");
+    if (p->n_shifts != 1) return fail(AM_EINVAL, "am_lstm_upload: the recurrent path takes un-spliced frames (n_shifts must be 1)");
+    if ((p->d_iv > 0) != (ivec != nullptr)) return fail(AM_EINVAL, "am_lstm_upload: i-vector argument does not match the frontend");
+    if (offsets[0] != 0) return fail(AM_EINVAL, "am_lstm_upload: offsets[0] must be 0");
+    am_engine* e = p->e;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    am_model* m0 = p->members[0];
+    const int64_t N = offsets[n_utts];
+    std::vector<int64_t> len(n_utts);
+    for (int u = 0; u < n_utts; ++u) {
+        const int64_t L = offsets[u + 1] - offsets[u];
+        if (L < 0) return fail(AM_EINVAL, "am_lstm_upload: offsets must be non-decreasing");
+        // predict_folds.py:39 edge-pads every utterance by `timedelay` rows, but its time loop stores only rows of
+        // utterances with (un-padded) length > t (predict_folds.py:50,61): the padded steps never reach an output and
+        // the last `timedelay` output frames of every utterance stay at their initial zeros.  So the device runs L steps.
+        len[u] = L;
+    }
+    // utterance slots: longest first (any order gives identical rows; this one keeps active slots contiguous)
+    std::vector<int> order(n_utts);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len[a] > len[b]; });
+    const int64_t T = n_utts > 0 ? len[order[0]] : 0;
+    p->step_off.assign(T + 1, 0);
+    p->n_active.assign(T, 0);
+    int active = n_utts;
+    for (int64_t t = 0; t < T; ++t) {
+        while (active > 0 && len[order[active - 1]] <= t) --active;
+        p->n_active[t] = active;
+        p->step_off[t + 1] = p->step_off[t] + active;
+    }
+    const int64_t NP = p->step_off[T];
+    if (NP > INT32_MAX || N > INT32_MAX) return fail(AM_EINVAL, "am_lstm_upload: shard too large");
+    std::vector<int> src(std::max<int64_t>(NP, 1)), dst(std::max<int64_t>(NP, 1));
+    for (int64_t t = 0; t < T; ++t)
+        for (int s = 0; s < p->n_active[t]; ++s) {
+            const int u = order[s];
+            const int64_t r = p->step_off[t] + s;
+            src[r] = (int)(offsets[u] + t);
+            dst[r] = t >= timedelay ? (int)(offsets[u] + t - timedelay) : -1;  // predict_folds.py:60-61
+        }
+    const int64_t rows_pad = round_up(std::max<int64_t>(NP, 1), GEMM_BM);
+    const int64_t rows_alloc = rows_pad + GEMM_BM;
+    int upad = 0, gw = 0;
+    for (auto* m : p->members)
+        for (int l = 0; l < m->n_layers; ++l) { upad = std::max(upad, m->L[l].U_pad); gw = std::max(gw, m->L[l].out_pad); }
+    AM_TRY(p->d_x.ensure(std::max<size_t>(sizeof(float) * N * p->D, 16)));
+    if (N > 0) HIP_TRY(hipMemcpyAsync(p->d_x.p, x, sizeof(float) * N * p->D, hipMemcpyHostToDevice, e->stream));
+    if (ivec) {
+        AM_TRY(p->d_ivec.ensure(std::max<size_t>(sizeof(float) * N * p->d_iv, 16)));
+        if (N > 0) HIP_TRY(hipMemcpyAsync(p->d_ivec.p, ivec, sizeof(float) * N * p->d_iv, hipMemcpyHostToDevice, e->stream));
+    }
+    AM_TRY(p->d_src.ensure(sizeof(int) * src.size()));
+    AM_TRY(p->d_dst.ensure(sizeof(int) * dst.size()));
+    HIP_TRY(hipMemcpyAsync(p->d_src.p, src.data(), sizeof(int) * src.size(), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(p->d_dst.p, dst.data(), sizeof(int) * dst.size(), hipMemcpyHostToDevice, e->stream));
+    AM_TRY(p->d_in.ensure(sizeof(float) * rows_alloc * m0->in_pad));
+    AM_TRY(p->d_G.ensure(sizeof(float) * rows_alloc * gw));
+    AM_TRY(p->d_H0.ensure(sizeof(float) * rows_alloc * upad));
+    AM_TRY(p->d_H1.ensure(sizeof(float) * rows_alloc * upad));
+    HIP_TRY(hipMemsetAsync(p->d_H0.p, 0, sizeof(float) * rows_alloc * upad, e->stream));
+    HIP_TRY(hipMemsetAsync(p->d_H1.p, 0, sizeof(float) * rows_alloc * upad, e->stream));
+    HIP_TRY(hipMemsetAsync(p->d_G.p, 0, sizeof(float) * rows_alloc * gw, e->stream));
+    AM_TRY(p->d_c.ensure(sizeof(float) * (round_up(std::max(n_utts, 1), 16)) * upad));
+    AM_TRY(p->d_acc.ensure(sizeof(float) * rows_pad * m0->C_pad));
+    if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(p->d_acc2.ensure(sizeof(float) * rows_pad * m0->C_pad));
+    AM_TRY(p->d_out.ensure(std::max<size_t>(sizeof(float) * N * m0->C, 16)));
+    if (timedelay > 0 && N > 0) HIP_TRY(hipMemsetAsync(p->d_out.p, 0, sizeof(float) * N * m0->C, e->stream));  // yb = np.zeros(...)
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    p->n = N; p->n_packed = NP; p->n_slots = n_utts; p->has_ivec = ivec != nullptr;
+    p->mode = 2;
+    return AM_OK;
+}
+
+extern "C" int am_lstm_run(am_pipeline* p)
+{
+    if (!p || p->mode != 2) return fail(AM_EINVAL, "am_lstm_run: nothing uploaded (am_lstm_upload)");
+    am_engine* e = p->e;
+    HIP_TRY(hipSetDevice(e->device));
+    if (p->n_packed == 0) return AM_OK;
+    am_model* m0 = p->members[0];
+    const int64_t NP = p->n_packed, rows_pad = round_up(NP, GEMM_BM);
+    const int64_t T = (int64_t)p->n_active.size();
+    GatherArgs ga{};
+    ga.x = p->d_x.as<float>(); ga.ivec = p->has_ivec ? p->d_ivec.as<float>() : nullptr; ga.src = p->d_src.as<int>();
+    ga.n = NP; ga.n_pad = rows_pad; ga.D = p->D;
+    ga.add = p->has_ft ? p->d_add.as<float>() : nullptr; ga.scale = p->has_ft ? p->d_scale.as<float>() : nullptr;
+    ga.d_iv = p->d_iv; ga.out = p->d_in.as<float>(); ga.ldo = m0->in_pad;
+    AM_TRY(run_kernel(e, K_GATHER_FT, [&] { return launch_gather_ft(e->stream, ga); }));
+    for (int mi = 0; mi < (int)p->members.size(); ++mi) {
+        am_model* m = p->members[mi];
+        const float* A = p->d_in.as<float>();
+        int lda = m->in_pad;
+        for (int l = 0; l < m->n_layers; ++l) {
+            Layer& Ly = m->L[l];
+            GemmArgs g{};
+            g.A = A; g.lda = lda; g.W = Ly.W.as<float>(); g.ldw = Ly.in_pad; g.bias = Ly.b.as<float>();
+            g.C = p->d_G.as<float>(); g.ldc = Ly.out_pad; g.M_pad = (int)rows_pad; g.N_pad = Ly.out_pad; g.K_pad = Ly.in_pad;
+            g.epi = EPI_LINEAR; g.alpha = 1.f;
+            AM_TRY(run_kernel(e, K_LSTM_UPWARD, [&] { return launch_gemm(e->stream, g); }));
+            float* H = ((l & 1) ? p->d_H1 : p->d_H0).as<float>();
+            for (int64_t t = 0; t < T; ++t) {
+                LstmStepArgs s{};
+                s.G = p->d_G.as<float>() + p->step_off[t] * Ly.out_pad;
+                s.Hprev = t > 0 ? H + p->step_off[t - 1] * Ly.U_pad : H;
+                s.Wlat = Ly.Wlat.as<float>(); s.Cst = p->d_c.as<float>();
+                s.Hout = H + p->step_off[t] * Ly.U_pad;
+                s.n_active = p->n_active[t]; s.U_pad = Ly.U_pad; s.first = t == 0;
+                AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_step(e->stream, s); }));
+            }
+            A = H; lda = Ly.U_pad;
+        }
+        Layer& Lo = m->L[m->n_layers];
+        GemmArgs g{};
+        g.A = A; g.lda = lda; g.W = Lo.W.as<float>(); g.ldw = Lo.in_pad; g.bias = Lo.b.as<float>();
+        g.C = p->d_acc.as<float>(); g.ldc = m->C_pad; g.M_pad = (int)rows_pad; g.N_pad = Lo.out_pad; g.K_pad = Lo.in_pad;
+        g.epi = epilogue_mode(p, mi, &g.alpha);
+        AM_TRY(run_kernel(e, K_GEMM_OUT, [&] { return launch_gemm(e->stream, g); }));
+        if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(member_finish(p, mi, NP));
+    }
+    return final_finish(p, NP, p->d_out.as<float>(), p->d_dst.as<int>());
+}
+
+extern "C" int am_lstm_download(am_pipeline* p, float* y)
+{
+    if (!p || p->mode != 2 || !y) return fail(AM_EINVAL, "am_lstm_download: nothing to download");
+    am_engine* e = p->e;
+    HIP_TRY(hipSetDevice(e->device));
+    if (p->n > 0) HIP_TRY(hipMemcpyAsync(y, p->d_out.p, sizeof(float) * p->n * p->members[0]->C, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return AM_OK;
+}
+
+extern "C" int am_forward_lstm(am_pipeline* p, const float* x, const float* ivec, const int64_t* offsets, int n_utts, int timedelay, float* y)
+{
+    AM_TRY(am_lstm_upload(p, x, ivec, offsets, n_utts, timedelay));
+    AM_TRY(am_lstm_run(p));
+    return am_lstm_download(p, y);
+}
+
+extern "C" int am_pipeline_output_shape(am_pipeline* p, int64_t* n, int* c)
+{
+    if (!p || p->mode == 0 || !n || !c) return fail(AM_EINVAL, "am_pipeline_output_shape: nothing uploaded");
+    *n = p->n; *c = p->members[0]->C;
+    return AM_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// stand-alone stage entry points
+// ----------------------------------------------------------------------------------------------------
+extern "C" int am_frontend_apply(am_pipeline* p, const float* x, const float* ivec, int64_t n, int halo_lo, int halo_hi, float* out)
+{
+    if (!p || p->D <= 0) return fail(AM_EINVAL, "am_frontend_apply: pipeline has no frontend");
+    if (!x || !out || n < 0 || halo_lo < 0 || halo_hi < 0) return fail(AM_EINVAL, "am_frontend_apply: bad argument");
+    if ((p->d_iv > 0) != (ivec != nullptr)) return fail(AM_EINVAL, "am_frontend_apply: i-vector argument does not match the frontend");
+    if (n == 0) return AM_OK;
+    am_engine* e = p->e;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const int width = p->n_shifts * p->D + p->d_iv;
+    const int ldo = (int)round_up(width, GEMM_BK);
+    const int64_t ext = halo_lo + n + halo_hi;
+    const int64_t n_pad = round_up(n, GEMM_BM);
+    AM_TRY(e->scratch[0].ensure(sizeof(float) * ext * p->D));
+    HIP_TRY(hipMemcpyAsync(e->scratch[0].p, x, sizeof(float) * ext * p->D, hipMemcpyHostToDevice, e->stream));
+    if (ivec) {
+        AM_TRY(e->scratch[1].ensure(sizeof(float) * n * p->d_iv));
+        HIP_TRY(hipMemcpyAsync(e->scratch[1].p, ivec, sizeof(float) * n * p->d_iv, hipMemcpyHostToDevice, e->stream));
+    }
+    AM_TRY(e->scratch[2].ensure(sizeof(float) * n_pad * ldo));
+    SpliceArgs s{};
+    s.x = e->scratch[0].as<float>(); s.ext_rows = ext; s.first = halo_lo; s.ivec = ivec ? e->scratch[1].as<float>() : nullptr;
+    s.row0 = 0; s.n = n; s.n_pad = n_pad; s.D = p->D; s.n_shifts = p->n_shifts; s.shifts = p->d_shifts.as<int>();
+    s.add = p->has_ft ? p->d_add.as<float>() : nullptr; s.scale = p->has_ft ? p->d_scale.as<float>() : nullptr;
+    s.d_iv = p->d_iv; s.out = e->scratch[2].as<float>(); s.ldo = ldo;
+    AM_TRY(run_kernel(e, K_SPLICE_FT, [&] { return launch_splice_ft(e->stream, s); }));
+    HIP_TRY(hipMemcpy2DAsync(out, sizeof(float) * width, e->scratch[2].p, sizeof(float) * ldo, sizeof(float) * width, n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return AM_OK;
+}
+
+extern "C" int am_lognormalise(am_engine* e, float* lp, int64_t n, int c, const float* ap)
+{
+    if (!e || !lp || n < 0 || c <= 0 || c > 2048) return fail(AM_EINVAL, "am_lognormalise: bad argument");
+    if (n == 0) return AM_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    AM_TRY(e->scratch[0].ensure(sizeof(float) * n * c));
+    HIP_TRY(hipMemcpyAsync(e->scratch[0].p, lp, sizeof(float) * n * c, hipMemcpyHostToDevice, e->stream));
+    if (ap) {
+        AM_TRY(e->scratch[1].ensure(sizeof(float) * c));
+        HIP_TRY(hipMemcpyAsync(e->scratch[1].p, ap, sizeof(float) * c, hipMemcpyHostToDevice, e->stream));
+    }
+    FinishArgs f{};
+    f.in = e->scratch[0].as<float>(); f.ldin = c; f.out = e->scratch[0].as<float>(); f.ldout = c;
+    f.n = n; f.C = c; f.prior = ap ? e->scratch[1].as<float>() : nullptr; f.normalise = 1;
+    AM_TRY(run_kernel(e, K_FINISH, [&] { return launch_finish(e->stream, f); }));
+    HIP_TRY(hipMemcpyAsync(lp, e->scratch[0].p, sizeof(float) * n * c, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return AM_OK;
+}
+
+extern "C" int am_linear(am_engine* e, const float* x, int64_t n, int in_dim, const float* W, const float* b, int out_dim, int act, float* y)
+{
+    if (!e || !x || !W || !y || n < 0 || in_dim <= 0 || out_dim <= 0 || act > AM_ACT_TANH) return fail(AM_EINVAL, "am_linear: bad argument");
+    if (n == 0) return AM_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const int kp = (int)round_up(in_dim, GEMM_BK), np = (int)round_up(out_dim, GEMM_BN);
+    const int64_t mp = round_up(n, GEMM_BM);
+    AM_TRY(e->scratch[0].ensure(sizeof(float) * mp * kp));
+    AM_TRY(e->scratch[1].ensure(sizeof(float) * (size_t)np * kp));
+    AM_TRY(e->scratch[2].ensure(sizeof(float) * np));
+    AM_TRY(e->scratch[3].ensure(sizeof(float) * mp * np));
+    HIP_TRY(hipMemsetAsync(e->scratch[0].p, 0, sizeof(float) * mp * kp, e->stream));
+    HIP_TRY(hipMemsetAsync(e->scratch[1].p, 0, sizeof(float) * (size_t)np * kp, e->stream));
+    HIP_TRY(hipMemsetAsync(e->scratch[2].p, 0, sizeof(float) * np, e->stream));
+    HIP_TRY(hipMemcpy2DAsync(e->scratch[0].p, sizeof(float) * kp, x, sizeof(float) * in_dim, sizeof(float) * in_dim, n, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpy2DAsync(e->scratch[1].p, sizeof(float) * kp, W, sizeof(float) * in_dim, sizeof(float) * in_dim, out_dim, hipMemcpyHostToDevice, e->stream));
+    if (b) HIP_TRY(hipMemcpyAsync(e->scratch[2].p, b, sizeof(float) * out_dim, hipMemcpyHostToDevice, e->stream));
+    GemmArgs g{};
+    g.A = e->scratch[0].as<float>(); g.lda = kp; g.W = e->scratch[1].as<float>(); g.ldw = kp; g.bias = e->scratch[2].as<float>();
+    g.C = e->scratch[3].as<float>(); g.ldc = np; g.M_pad = (int)mp; g.N_pad = np; g.K_pad = kp;
+    g.act = act < 0 ? 0 : act; g.epi = act < 0 ? EPI_LINEAR : EPI_ACT; g.alpha = 1.f;
+    AM_TRY(run_kernel(e, K_GEMM_HIDDEN, [&] { return launch_gemm(e->stream, g); }));
+    HIP_TRY(hipMemcpy2DAsync(y, sizeof(float) * out_dim, e->scratch[3].p, sizeof(float) * np, sizeof(float) * out_dim, n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return AM_OK;
+}

@@ -1,0 +1,85 @@
+// Internal interface between the C-ABI host layer (am_api.hip) and the gfx950 kernels (am_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace am {
+
+// kernel ids for the per-kernel event profile (am_profile_read)
+enum KernelId {
+    K_SPLICE_FT = 0,   // fused splice + (x+shift)*scale + i-vector passthrough
+    K_GEMM_HIDDEN = 1, // Linear + bias + activation (MFMA f32)
+    K_GEMM_OUT = 2,    // output Linear + bias (+ ensemble scale/accumulate) (MFMA f32)
+    K_FINISH = 3,      // combine divide / RPL4 / prior / log-softmax
+    K_GATHER_FT = 4,   // recurrent path: gather rows to time-major + transform
+    K_LSTM_UPWARD = 5, // hoisted upward GEMM of an LSTM layer (MFMA f32)
+    K_LSTM_STEP = 6,   // one recurrent step: h W_lat^T + gates
+    K_COUNT = 7
+};
+
+constexpr int GEMM_BM = 128;
+constexpr int GEMM_BN = 128;
+constexpr int GEMM_BK = 32;
+
+enum Epilogue {
+    EPI_ACT = 0,    // C = act(acc + bias)
+    EPI_LINEAR = 1, // C = acc + bias
+    EPI_SCALE = 2,  // C = (acc + bias) * alpha
+    EPI_ACCUM = 3   // C = C + (acc + bias)
+};
+
+struct GemmArgs {
+    const float* A; int lda;      // [M_pad, lda]  activations, K-contiguous
+    const float* W; int ldw;      // [N_pad, ldw]  weights in Chainer [out,in] layout, K-contiguous
+    const float* bias;            // [N_pad]
+    float* C; int ldc;            // [M_pad, ldc]
+    int M_pad, N_pad, K_pad;      // multiples of 128 / 128 / 32
+    int act;                      // AM_ACT_* (EPI_ACT only)
+    int epi; float alpha;
+};
+hipError_t init_kernels();  // once per device after hipSetDevice
+hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
+
+struct SpliceArgs {
+    const float* x; int64_t ext_rows; int64_t first;  // x: [ext_rows, D]; output row r reads x[first + r + shift]
+    const float* ivec;                                // [>= row0 + n, d_iv] or nullptr, indexed by (row0 + r)
+    int64_t row0; int64_t n; int64_t n_pad;           // rows [row0, row0+n) are real, [n, n_pad) are zero-filled
+    int D; int n_shifts; const int* shifts;           // device pointer
+    const float* add; const float* scale;             // device [n_shifts*D] or nullptr
+    int d_iv; float* out; int ldo;
+};
+hipError_t launch_splice_ft(hipStream_t s, const SpliceArgs& a);
+
+struct FinishArgs {
+    const float* in; int ldin;      // [n, ldin]
+    float* out; int64_t ldout;      // [*, ldout]
+    const int* row_map;             // device [n] destination row (<0 = skip) or nullptr (identity)
+    int64_t n; int C;
+    float divisor;                  // > 0: v = v / divisor first
+    const float* rpl_w; const float* rpl_b; const float* rpl_lb; // RPL4 or nullptr
+    const float* prior;             // [C] or nullptr
+    int normalise;                  // apply y - logsum(y)
+    int accumulate;                 // out += result instead of out = result
+};
+hipError_t launch_finish(hipStream_t s, const FinishArgs& a);
+
+struct GatherArgs {
+    const float* x; const float* ivec;  // [N, D], [N, d_iv] or nullptr
+    const int* src;                     // device [n] source frame per packed row
+    int64_t n; int64_t n_pad;
+    int D; const float* add; const float* scale; int d_iv;
+    float* out; int ldo;
+};
+hipError_t launch_gather_ft(hipStream_t s, const GatherArgs& a);
+
+struct LstmStepArgs {
+    const float* G;      // [>= rows, 4*U_pad] upward pre-activations of THIS step's rows, gate-tiled layout
+    const float* Hprev;  // [>= rows, U_pad]   previous step's outputs (same utterance order), unused if first
+    const float* Wlat;   // [4*U_pad, U_pad]   gate-tiled rows
+    float* Cst;          // [>= rows, U_pad]   cell state per utterance slot
+    float* Hout;         // [>= rows, U_pad]
+    int n_active; int U_pad; int first;
+};
+hipError_t launch_lstm_step(hipStream_t s, const LstmStepArgs& a);
+
+}  // namespace am

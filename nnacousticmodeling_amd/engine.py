@@ -1,0 +1,291 @@
+"""Object wrappers over the C ABI: Engine (one GPU), Model (weights in HBM), Pipeline (frontend + members + epilogue).
+
+All arithmetic happens in libamfwd.so's HIP kernels; this module only marshals numpy arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (AM_ACT_RELU, AM_ACT_SIGMOID, AM_ACT_TANH, AM_COMBINE_LOGITS, AM_COMBINE_LOGPOST, AM_NET_FF, AM_NET_LSTM,
+                   AmError, c_float_p, c_int64_p, c_int_p, check)
+
+ACTIVATIONS = {"relu": AM_ACT_RELU, "sigmoid": AM_ACT_SIGMOID, "tanh": AM_ACT_TANH}
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(c_float_p)
+
+
+def device_count():
+    return int(_lib.load().am_device_count())
+
+
+class Engine:
+    """One MI355X: compute stream, events, workspace.  Raises AmError when the device is not a gfx950 GPU."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        check(self._lib.am_engine_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.am_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def name(self):
+        buf = C.create_string_buffer(256)
+        check(self._lib.am_engine_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    def synchronize(self):
+        check(self._lib.am_engine_synchronize(self._h))
+
+    def record(self, slot):
+        check(self._lib.am_event_record(self._h, int(slot)))
+
+    def elapsed_ms(self, a, b):
+        ms = C.c_float()
+        check(self._lib.am_event_elapsed_ms(self._h, int(a), int(b), C.byref(ms)))
+        return float(ms.value)
+
+    def profile(self, on=True):
+        check(self._lib.am_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self):
+        check(self._lib.am_profile_reset(self._h))
+
+    def profile_read(self):
+        """-> {kernel name: (launches, total ms)} since the last reset."""
+        calls = (C.c_int64 * _lib.AM_KERNEL_ID_MAX)()
+        ms = (C.c_double * _lib.AM_KERNEL_ID_MAX)()
+        check(self._lib.am_profile_read(self._h, calls, ms))
+        out = {}
+        for i in range(_lib.AM_KERNEL_ID_MAX):
+            nm = self._lib.am_kernel_name(i)
+            if nm is not None and calls[i]:
+                out[nm.decode()] = (int(calls[i]), float(ms[i]))
+        return out
+
+    # stand-alone stage entry points --------------------------------------------------------------
+    def lognormalise(self, lp, ap=None):
+        lp = np.array(lp, dtype=np.float32, order="C", copy=True)
+        ap_ = None if ap is None else _f32(np.asarray(ap).reshape(-1))
+        check(self._lib.am_lognormalise(self._h, _fp(lp), lp.shape[0], lp.shape[1], _fp(ap_)))
+        return lp
+
+    def linear(self, x, w, b=None, act=None):
+        x, w = _f32(x), _f32(w)
+        b_ = None if b is None else _f32(b)
+        y = np.empty((x.shape[0], w.shape[0]), dtype=np.float32)
+        a = -1 if act is None else ACTIVATIONS[act]
+        check(self._lib.am_linear(self._h, _fp(x), x.shape[0], x.shape[1], _fp(w), _fp(b_), w.shape[0], a, _fp(y)))
+        return y
+
+
+class Model:
+    """A network's weights resident on the engine's GPU.
+
+    ``params``: Chainer npz keys without the ``predictor/`` prefix:
+    ff   -> layer_{l}/W [units,in], layer_{l}/b, out/W [C,units], out/b
+    lstm -> layer_{l}/upward/W [4U,in], layer_{l}/upward/b [4U], layer_{l}/lateral/W [4U,U], out/W, out/b
+    Layer input sizes are taken from the stored shapes, as ``L.Linear(None, ...)`` does.
+    """
+
+    def __init__(self, engine, network, layers, params, activation="relu"):
+        self.engine = engine
+        self.network = network
+        self.layers = int(layers)
+        self._lib = engine._lib
+        if activation not in ACTIVATIONS:
+            raise ValueError("Wrong activation function specified")
+        ws, bs, lats = [], [], []
+        if network == "ff":
+            kind = AM_NET_FF
+            for l in range(self.layers):
+                ws.append(_f32(params["layer_%d/W" % l]))
+                bs.append(_f32(params["layer_%d/b" % l]))
+        elif network == "lstm":
+            kind = AM_NET_LSTM
+            for l in range(self.layers):
+                ws.append(_f32(params["layer_%d/upward/W" % l]))
+                bs.append(_f32(params["layer_%d/upward/b" % l]))
+                lats.append(_f32(params["layer_%d/lateral/W" % l]))
+            _check_gate_layout(bs)
+        else:
+            raise ValueError("network %r is not supported by the MI355X engine (supported: ff, lstm)" % network)
+        ws.append(_f32(params["out/W"]))
+        bs.append(_f32(params["out/b"]))
+        n = self.layers + 1
+        in_dims = (C.c_int * n)(*[w.shape[1] for w in ws])
+        out_dims = (C.c_int * n)(*[w.shape[0] for w in ws])
+        w_arr = (c_float_p * n)(*[_fp(w) for w in ws])
+        b_arr = (c_float_p * n)(*[_fp(b) for b in bs])
+        lat_arr = (c_float_p * max(len(lats), 1))(*[_fp(w) for w in lats]) if lats else None
+        h = C.c_void_p()
+        check(self._lib.am_model_create(engine._h, kind, self.layers, ACTIVATIONS[activation], in_dims, out_dims,
+                                        w_arr, b_arr, lat_arr, C.byref(h)))
+        self._h = h
+        self.in_dim = int(ws[0].shape[1])
+        self.num_classes = int(ws[-1].shape[0])
+        self.recurrent = network == "lstm"
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.am_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _check_gate_layout(upward_biases):
+    """Loader self-check from SURVEY.md Appendix A.3: Chainer interleaves gates (column 4u+k) and initialises the forget
+    bias (k = 2) to 1; warn loudly when a contiguous-block reading of the bias looks more plausible."""
+    import warnings
+    for l, b in enumerate(upward_biases):
+        u = b.shape[0] // 4
+        if u < 4:
+            continue
+        inter = b.reshape(u, 4).mean(axis=0)
+        block = b.reshape(4, u).mean(axis=1)
+        if np.argmax(block) == 2 and block[2] - np.delete(block, 2).max() > 0.5 and np.argmax(inter) != 2:
+            warnings.warn("LSTM layer %d: upward/b looks gate-blocked, not gate-interleaved as Chainer stores it; "
+                          "posteriors will be wrong if the file was not written by Chainer" % l)
+
+
+class Pipeline:
+    """Frontend + member networks + epilogue, plus the resident I/O buffers of one shard."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self._lib = engine._lib
+        h = C.c_void_p()
+        check(self._lib.am_pipeline_create(engine._h, C.byref(h)))
+        self._h = h
+        self._members = []
+        self.num_classes = None
+        self.d_iv = 0
+        self.D = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.am_pipeline_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # configuration ---------------------------------------------------------------------------------
+    def set_frontend(self, D, shifts, add_shift=None, rescale=None, d_iv=0):
+        shifts = [int(s) for s in shifts]
+        arr = (C.c_int * len(shifts))(*shifts)
+        a = None if add_shift is None else _f32(add_shift)
+        r = None if rescale is None else _f32(rescale)
+        if a is not None and (a.size != len(shifts) * D or r is None or r.size != a.size):
+            raise ValueError("operands could not be broadcast together: transform has %d entries, spliced frame has %d"
+                             % (a.size, len(shifts) * D))
+        check(self._lib.am_pipeline_set_frontend(self._h, int(D), len(shifts), arr, _fp(a), _fp(r), int(d_iv)))
+        self.D, self.shifts, self.d_iv = int(D), shifts, int(d_iv)
+        self.max_shift = max(abs(s) for s in shifts)
+
+    def set_members(self, members, has_master=False, combine=AM_COMBINE_LOGITS):
+        members = list(members)
+        arr = (C.c_void_p * len(members))(*[m._h for m in members])
+        check(self._lib.am_pipeline_set_members(self._h, len(members), arr, 1 if has_master else 0, int(combine)))
+        self._members = members
+        self.num_classes = members[0].num_classes
+        self.recurrent = members[0].recurrent
+
+    def set_rpl4(self, w, b, lb):
+        if w is None:
+            check(self._lib.am_pipeline_set_rpl4(self._h, None, None, None))
+            return
+        w, b, lb = (_f32(np.asarray(v).reshape(-1)) for v in (w, b, lb))
+        check(self._lib.am_pipeline_set_rpl4(self._h, _fp(w), _fp(b), _fp(lb)))
+
+    def set_prior(self, ap):
+        ap_ = None if ap is None else _f32(np.asarray(ap).reshape(-1))
+        check(self._lib.am_pipeline_set_prior(self._h, _fp(ap_)))
+
+    def set_normalise(self, on):
+        check(self._lib.am_pipeline_set_normalise(self._h, 1 if on else 0))
+
+    # feed-forward ----------------------------------------------------------------------------------
+    def ff_upload(self, x_ext, ivec, n, halo_lo, halo_hi):
+        x_ext = _f32(x_ext)
+        iv = None if ivec is None else _f32(ivec)
+        if x_ext.shape != (halo_lo + n + halo_hi, self.D):
+            raise ValueError("x must be [halo_lo + n + halo_hi, D]")
+        check(self._lib.am_ff_upload(self._h, _fp(x_ext), _fp(iv), int(n), int(halo_lo), int(halo_hi)))
+        self._n = int(n)
+
+    def ff_run(self):
+        check(self._lib.am_ff_run(self._h))
+
+    def ff_download(self, out=None):
+        y = out if out is not None else np.empty((self._n, self.num_classes), dtype=np.float32)
+        assert y.dtype == np.float32 and y.flags.c_contiguous and y.shape == (self._n, self.num_classes)
+        check(self._lib.am_ff_download(self._h, _fp(y)))
+        return y
+
+    def forward_ff(self, x_ext, ivec=None, n=None, halo_lo=0, halo_hi=0, out=None):
+        n = x_ext.shape[0] - halo_lo - halo_hi if n is None else n
+        self.ff_upload(x_ext, ivec, n, halo_lo, halo_hi)
+        self.ff_run()
+        return self.ff_download(out)
+
+    # recurrent -------------------------------------------------------------------------------------
+    def lstm_upload(self, x, ivec, offsets, timedelay=0):
+        x = _f32(x)
+        iv = None if ivec is None else _f32(ivec)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        if off[-1] != x.shape[0]:
+            raise ValueError("offsets[-1] must equal the number of frames")
+        check(self._lib.am_lstm_upload(self._h, _fp(x), _fp(iv), off.ctypes.data_as(c_int64_p), len(off) - 1, int(timedelay)))
+        self._n = int(x.shape[0])
+
+    def lstm_run(self):
+        check(self._lib.am_lstm_run(self._h))
+
+    def lstm_download(self, out=None):
+        y = out if out is not None else np.empty((self._n, self.num_classes), dtype=np.float32)
+        assert y.dtype == np.float32 and y.flags.c_contiguous and y.shape == (self._n, self.num_classes)
+        check(self._lib.am_lstm_download(self._h, _fp(y)))
+        return y
+
+    def forward_lstm(self, x, offsets, ivec=None, timedelay=0, out=None):
+        self.lstm_upload(x, ivec, offsets, timedelay)
+        self.lstm_run()
+        return self.lstm_download(out)
+
+    # stage entry point -------------------------------------------------------------------------------
+    def frontend_apply(self, x_ext, ivec=None, n=None, halo_lo=0, halo_hi=0):
+        x_ext = _f32(x_ext)
+        iv = None if ivec is None else _f32(ivec)
+        n = x_ext.shape[0] - halo_lo - halo_hi if n is None else n
+        out = np.empty((n, len(self.shifts) * self.D + self.d_iv), dtype=np.float32)
+        check(self._lib.am_frontend_apply(self._h, _fp(x_ext), _fp(iv), int(n), int(halo_lo), int(halo_hi), _fp(out)))
+        return out

@@ -1,0 +1,203 @@
+"""GPU parity of the whole device path (frontend -> network -> epilogue) against the CPU oracle, through the C ABI.
+
+The network arithmetic has no reference-held golden vector (Chainer absent: "parity unpinned", see oracle header);
+the oracle here is the self-oracle restating Chainer's CPU semantics, with a float64 shadow for error budgeting.
+"""
+import numpy as np
+import pytest
+
+from oracle import am_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # north_star tolerance: max-abs on fp32 log-posteriors
+
+
+def _mk(eng, network, layers, params, act="relu"):
+    from nnacousticmodeling_amd.engine import Model
+    return Model(eng, network, layers, params, act)
+
+
+def _pipe(eng):
+    from nnacousticmodeling_amd.engine import Pipeline
+    return Pipeline(eng)
+
+
+def _ft(path):
+    return orc.load_kaldi_feature_transform(path)
+
+
+@pytest.mark.parametrize("n", [1, 127, 300, 1024, 2500])
+def test_mlp_predict_surface_b(engine, real_ft_path, n):
+    """predict_folds FF path: splice(5) + ft + 4x1024 MLP + y - logsum(y)."""
+    rng = np.random.default_rng(n)
+    ft = _ft(real_ft_path)
+    params = orc.make_mlp_params(rng, 440, 1024, 4, 1909)
+    x = rng.standard_normal((n, 40)).astype(np.float32)
+    want = orc.predict(orc.MLP(params, 4), x, None, False, 11, 0, ft)
+    want64 = orc.predict(orc.MLP(params, 4, dtype=np.float64), x, None, False, 11, 0, ft)
+    p = _pipe(engine)
+    p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+    p.set_members([_mk(engine, "ff", 4, params)])
+    got = p.forward_ff(x)
+    assert got.shape == (n, 1909) and got.dtype == np.float32
+    assert np.max(np.abs(got - want)) <= TOL
+    assert np.max(np.abs(got - want64)) <= TOL
+
+
+def test_mlp_evaluate_surface_a_with_priors(engine, real_ft_path, real_priors):
+    """evaluate FF path: per-utterance forward, y - ap, y - logsum(y) (evaluateModelForTest.py:98-112)."""
+    rng = np.random.default_rng(7)
+    ft = _ft(real_ft_path)
+    params = orc.make_mlp_params(rng, 440, 1024, 4, 1909)
+    offsets = orc.make_offsets(rng, 12, 3000)
+    x = rng.standard_normal((3000, 40)).astype(np.float32)
+    data = orc.evaluate_frontend(x, 5, ft)
+    want = np.concatenate(orc.evaluate_posteriors(orc.MLP(params, 4), data, offsets, ap=real_priors))
+    p = _pipe(engine)
+    p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+    p.set_members([_mk(engine, "ff", 4, params)])
+    p.set_prior(real_priors)
+    got = p.forward_ff(x)
+    assert np.max(np.abs(got - want)) <= TOL
+
+
+def test_mlp_6x2048_fmllr_ivectors(engine, real_ft_path):
+    """configs[2]: 6x2048 on 440 + 100 i-vector columns (concatenated after the transform, evaluate.py:169-171)."""
+    rng = np.random.default_rng(11)
+    ft = _ft(real_ft_path)
+    params = orc.make_mlp_params(rng, 540, 2048, 6, 1909)
+    n = 700
+    x = rng.standard_normal((n, 40)).astype(np.float32)
+    iv = rng.standard_normal((n, 100)).astype(np.float32)
+    data = orc.evaluate_frontend(x, 5, ft, iv)
+    want = orc.log_normalise(orc.MLP(params, 6)(data))
+    p = _pipe(engine)
+    p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"], 100)
+    p.set_members([_mk(engine, "ff", 6, params)])
+    got = p.forward_ff(x, iv)
+    assert np.max(np.abs(got - want)) <= TOL
+
+
+@pytest.mark.parametrize("act", ["sigmoid", "tanh"])
+def test_mlp_other_activations_and_odd_sizes(engine, act):
+    rng = np.random.default_rng(3)
+    params = orc.make_mlp_params(rng, 5 * 13, 200, 2, 39)  # monophone-sized head, nothing a multiple of a tile
+    x = rng.standard_normal((333, 13)).astype(np.float32)
+    want = orc.predict(orc.MLP(params, 2, act), x, None, False, 5, 0, None)
+    p = _pipe(engine)
+    p.set_frontend(13, range(-2, 3))
+    p.set_members([_mk(engine, "ff", 2, params, act)])
+    got = p.forward_ff(x)
+    assert np.max(np.abs(got - want)) <= TOL
+
+
+def test_ff_shards_with_halo_equal_whole(engine, real_ft_path):
+    rng = np.random.default_rng(21)
+    ft = _ft(real_ft_path)
+    params = orc.make_mlp_params(rng, 440, 256, 2, 1909)
+    n = 1000
+    x = rng.standard_normal((n, 40)).astype(np.float32)
+    p = _pipe(engine)
+    p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+    p.set_members([_mk(engine, "ff", 2, params)])
+    whole = p.forward_ff(x)
+    parts = []
+    for lo, hi in ((0, 333), (333, 640), (640, n)):
+        h_lo, h_hi = min(5, lo), min(5, n - hi)
+        parts.append(p.forward_ff(x[lo - h_lo:hi + h_hi], None, hi - lo, h_lo, h_hi))
+    assert np.array_equal(np.concatenate(parts), whole)  # row-independent arithmetic: bit-identical
+
+
+@pytest.mark.parametrize("timedelay", [0, 5])
+def test_lstm_predict_surface_b(engine, real_ft_path, timedelay):
+    """predict_folds recurrent path incl. time-delay edge padding (predict_folds.py:28-68); 3x512 on 40 dims."""
+    rng = np.random.default_rng(31 + timedelay)
+    ft = orc.centre_frame_transform(_ft(real_ft_path))
+    params = orc.make_lstm_params(rng, 40, 512, 3, 1909)
+    offsets = orc.make_offsets(rng, 9, 700, lo=20, hi=200)
+    x = rng.standard_normal((700, 40)).astype(np.float32)
+    want = orc.predict(orc.LSTM(params, 3), x, offsets, True, 1, timedelay, ft)
+    p = _pipe(engine)
+    p.set_frontend(40, [0], ft["addShift"], ft["rescale"])
+    p.set_members([_mk(engine, "lstm", 3, params)])
+    got = p.forward_lstm(x, offsets, timedelay=timedelay)
+    assert np.max(np.abs(got - want)) <= TOL
+
+
+def test_lstm_evaluate_surface_a(engine, real_ft_path, real_priors):
+    """evaluate recurrent path: no time-delay shift, priors subtracted (evaluateModelForTest.py:52-94)."""
+    rng = np.random.default_rng(41)
+    ft = orc.centre_frame_transform(_ft(real_ft_path))
+    params = orc.make_lstm_params(rng, 40, 96, 2, 1909)  # U = 96 is not a multiple of 64: exercises unit padding
+    offsets = orc.make_offsets(rng, 20, 900, lo=5, hi=120)
+    x = rng.standard_normal((900, 40)).astype(np.float32)
+    data = orc.evaluate_frontend(x, 0, ft)
+    want = np.concatenate(orc.evaluate_posteriors(orc.LSTM(params, 2), data, offsets, ap=real_priors, rnn=True))
+    want64 = np.concatenate(orc.evaluate_posteriors(orc.LSTM(params, 2, dtype=np.float64), data, offsets, ap=real_priors.astype(np.float64), rnn=True))
+    p = _pipe(engine)
+    p.set_frontend(40, [0], ft["addShift"], ft["rescale"])
+    p.set_members([_mk(engine, "lstm", 2, params)])
+    p.set_prior(real_priors)
+    got = p.forward_lstm(x, offsets)
+    assert np.max(np.abs(got - want)) <= TOL
+    assert np.max(np.abs(got - want64)) <= TOL
+
+
+def test_ensemble_logit_average_and_rpl4(engine, real_ft_path, real_priors):
+    """NNWithRPL (evaluate.py:35-51): (K*master + sum folds)/(2K), folds only, and the RPL4 epilogue (RPL.py:68-74)."""
+    rng = np.random.default_rng(51)
+    ft = _ft(real_ft_path)
+    n = 400
+    x = rng.standard_normal((n, 40)).astype(np.float32)
+    data = orc.evaluate_frontend(x, 5, ft)
+    plist = [orc.make_mlp_params(rng, 440, 256, 2, 1909) for _ in range(4)]
+    rpl = {"W": (0.05 * rng.standard_normal((1, 1909))).astype(np.float32),
+           "b": (0.1 * rng.standard_normal((1, 1909))).astype(np.float32),
+           "lb": np.full((1, 1909), -20.0, dtype=np.float32) + rng.standard_normal((1, 1909)).astype(np.float32)}
+    omodels = [orc.MLP(q, 2) for q in plist]
+    gmodels = [_mk(engine, "ff", 2, q) for q in plist]
+    cases = [
+        (orc.NNWithRPL(omodels[0], omodels[1:], None), gmodels, True, None),
+        (orc.NNWithRPL(None, omodels[1:], None), gmodels[1:], False, None),
+        (orc.NNWithRPL(omodels[0], [], orc.RPL4(rpl)), gmodels[:1], True, rpl),
+        (orc.NNWithRPL(omodels[0], omodels[1:], orc.RPL4(rpl)), gmodels, True, rpl),
+    ]
+    for omodel, members, has_master, r in cases:
+        want = np.concatenate(orc.evaluate_posteriors(omodel, data, np.array([0, 150, n]), ap=real_priors))
+        p = _pipe(engine)
+        p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+        p.set_members(members, has_master=has_master)
+        if r is not None:
+            p.set_rpl4(r["W"], r["b"], r["lb"])
+        p.set_prior(real_priors)
+        got = p.forward_ff(x)
+        assert np.max(np.abs(got - want)) <= TOL
+
+
+def test_fold_average_dev_mode(engine, real_ft_path):
+    """predict_folds --fold-output-dev: mean of per-fold log-posteriors, renormalised (predict_folds.py:199-220)."""
+    from nnacousticmodeling_amd._lib import AM_COMBINE_LOGPOST
+    rng = np.random.default_rng(61)
+    ft = _ft(real_ft_path)
+    x = rng.standard_normal((500, 40)).astype(np.float32)
+    plist = [orc.make_mlp_params(rng, 440, 128, 2, 1909) for _ in range(3)]
+    want = orc.fold_average_dev([orc.MLP(q, 2) for q in plist], x, None, False, 11, 0, ft)
+    p = _pipe(engine)
+    p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+    p.set_members([_mk(engine, "ff", 2, q) for q in plist], combine=AM_COMBINE_LOGPOST)
+    got = p.forward_ff(x)
+    assert np.max(np.abs(got - want)) <= TOL
+
+
+def test_api_errors(engine):
+    from nnacousticmodeling_amd._lib import AmError
+    rng = np.random.default_rng(0)
+    p = _pipe(engine)
+    p.set_frontend(40, range(-5, 6))
+    m = _mk(engine, "ff", 1, orc.make_mlp_params(rng, 100, 64, 1, 39))
+    p.set_members([m])
+    with pytest.raises(AmError):  # frontend width 440 != network input 100
+        p.forward_ff(np.zeros((10, 40), dtype=np.float32))
+    with pytest.raises(ValueError):
+        _mk(engine, "gru", 1, {})
