@@ -317,7 +317,7 @@ extern "C" int am_model_create(am_engine* e, int kind, int n_layers, int activat
     m->in_dim = in_dims[0];
     m->in_pad = (int)round_up(in_dims[0], GEMM_BK);
     m->C = out_dims[n_layers];
-    m->C_pad = (int)round_up(m->C, GEMM_BN);
+    m->C_pad = gemm_n_pad(m->C);
     int rc = AM_OK;
     for (int l = 0; l <= n_layers && rc == AM_OK; ++l) {
         Layer& Ly = m->L[l];
@@ -327,7 +327,7 @@ extern "C" int am_model_create(am_engine* e, int kind, int n_layers, int activat
         else Ly.in_pad = (kind == AM_NET_LSTM) ? m->L[l - 1].U_pad : m->L[l - 1].out_pad;
         if (lstm_layer) {
             Ly.U = Ly.out / 4;
-            Ly.U_pad = (int)round_up(Ly.U, 32);
+            Ly.U_pad = (int)round_up(Ly.U, 64);  // 4*U_pad is then a multiple of 256 (GEMM tile) and U_pad of 16 (step tile)
             Ly.out_pad = 4 * Ly.U_pad;
             std::vector<float> w((size_t)Ly.out_pad * Ly.in_pad, 0.f), bb(Ly.out_pad, 0.f), wl((size_t)Ly.out_pad * Ly.U_pad, 0.f);
             for (int u = 0; u < Ly.U; ++u)
@@ -342,7 +342,7 @@ extern "C" int am_model_create(am_engine* e, int kind, int n_layers, int activat
             if ((rc = upload(e, Ly.Wlat, wl)) != AM_OK) break;
             m->max_width = std::max(m->max_width, Ly.U_pad);
         } else {
-            Ly.out_pad = (int)round_up(Ly.out, GEMM_BN);
+            Ly.out_pad = gemm_n_pad(Ly.out);
             std::vector<float> w((size_t)Ly.out_pad * Ly.in_pad, 0.f), bb(Ly.out_pad, 0.f);
             for (int o = 0; o < Ly.out; ++o) memcpy(&w[(size_t)o * Ly.in_pad], W[l] + (size_t)o * Ly.in, sizeof(float) * Ly.in);
             memcpy(bb.data(), b[l], sizeof(float) * Ly.out);
@@ -845,7 +845,7 @@ extern "C" int am_linear(am_engine* e, const float* x, int64_t n, int in_dim, co
     if (n == 0) return AM_OK;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    const int kp = (int)round_up(in_dim, GEMM_BK), np = (int)round_up(out_dim, GEMM_BN);
+    const int kp = (int)round_up(in_dim, GEMM_BK), np = gemm_n_pad(out_dim);
     const int64_t mp = round_up(n, GEMM_BM);
     AM_TRY(e->scratch[0].ensure(sizeof(float) * mp * kp));
     AM_TRY(e->scratch[1].ensure(sizeof(float) * (size_t)np * kp));

@@ -17,9 +17,9 @@ enum KernelId {
     K_COUNT = 7
 };
 
-constexpr int GEMM_BM = 128;
-constexpr int GEMM_BN = 128;
-constexpr int GEMM_BK = 32;
+constexpr int GEMM_BM = 256;  // rows per block tile: every activation matrix is padded to a multiple of this
+constexpr int GEMM_BK = 32;   // every K (leading dimension) is padded to a multiple of this
+int gemm_n_pad(int n);         // padded output width: multiple of 256, or of 384 when that wastes less
 
 enum Epilogue {
     EPI_ACT = 0,    // C = act(acc + bias)
@@ -33,7 +33,7 @@ struct GemmArgs {
     const float* W; int ldw;      // [N_pad, ldw]  weights in Chainer [out,in] layout, K-contiguous
     const float* bias;            // [N_pad]
     float* C; int ldc;            // [M_pad, ldc]
-    int M_pad, N_pad, K_pad;      // multiples of 128 / 128 / 32
+    int M_pad, N_pad, K_pad;      // multiples of GEMM_BM / (256 or 384) / GEMM_BK
     int act;                      // AM_ACT_* (EPI_ACT only)
     int epi; float alpha;
 };

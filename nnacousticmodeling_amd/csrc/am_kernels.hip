@@ -24,29 +24,31 @@ __device__ __forceinline__ float am_activate(float v, int act) {
 // ---------------------------------------------------------------------------------------------------
 // Linear layer:  C[M,N] = epi(A[M,K] * W[N,K]^T + bias[N])   -- "NT" GEMM, both operands K-contiguous.
 //
-// Exact-f32 MFMA (v_mfma_f32_32x32x2_f32, 64 cycles / SIMD, one k-pair per instruction).
-// Block = 256 threads = 4 waves as 2(M) x 2(N); block tile 128 x 128, BK = 32; each wave owns 64 x 64 =
-// 2 x 2 MFMA tiles of 32 x 32 (64 accumulator VGPRs).
-// Staging: global_load_lds_dwordx4 straight into LDS (no VGPR round trip), 2 stages of 32 KiB -> 2 blocks/CU.
-// LDS image per operand: [128 rows][32 floats] = 128-B rows, 16-B chunk index XOR-swizzled with (row>>1)&7 so a
-// ds_read_b128 lane group (16 distinct rows, same chunk) touches 16 distinct 16-B slots of the 256-B bank row.
+// Exact-f32 MFMA (v_mfma_f32_32x32x2_f32: 64 cycles / SIMD, one k-pair per instruction, bitwise an fmaf chain).
+// Block = 512 threads = 8 waves as 4(M) x 2(N); block tile 256 x BN (BN = 256 for hidden layers, 384 for the
+// 1909-class output layer: 1920 = 5 x 384, no column padding waste); each wave owns 64 x BN/2 = 2 x NI MFMA tiles.
+// Tile choice measured in tools/gemm_lab.hip on M=196608: 128x128 tiles 135.5 TF/s, 256x256 142.8, 256x384 142.1
+// (the LDS-DMA stream costs MFMA issue slots in proportion to bytes per flop; a no-load ablation runs 149).
+// Staging: global_load_lds_dwordx4 straight into LDS (no VGPR round trip), 2 stages.
+// LDS image per operand: [rows][BK floats]; the 16-B chunk index is XOR-swizzled with the row so a ds_read_b128
+// lane group (16 distinct rows, same chunk) touches 16 distinct 16-B slots of the 256-B bank row.
 // LDS-DMA writes lane-linearly, so the swizzle is applied to the per-lane SOURCE address (guide rule 21).
 // K permutation: lane (i = lane&31, h = lane>>5) reads 4 consecutive floats k = 8t + 4h + j (one ds_read_b128)
 // and feeds them to MFMA steps j = 0..3; A and W use the same map, so each MFMA pairs equal k.
+// Loop: [vmcnt(0)] [raw s_barrier] [issue stage kt+1, interleaved with] [MFMAs of stage kt].
 // ---------------------------------------------------------------------------------------------------
-constexpr int GEMM_STAGE_BYTES = (GEMM_BM + GEMM_BN) * GEMM_BK * 4;  // 32 KiB
-constexpr int GEMM_LDS_BYTES = 2 * GEMM_STAGE_BYTES;                 // 64 KiB
+constexpr int GEMM_WM = 4, GEMM_WN = 2, GEMM_THREADS = 64 * GEMM_WM * GEMM_WN;
 
 // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 // MODE: 0 relu, 1 sigmoid, 2 tanh, 3 linear, 4 scale by alpha, 5 accumulate into C.
-template <int MODE>
-__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const float* __restrict__ bias, float* __restrict__ C,
+template <int MODE, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NI], const float* __restrict__ bias, float* __restrict__ C,
                                               int ldc, int erow, int ecol, float alpha)
 {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
             const int col = ecol + ni * 32;
             const float bv = bias[col];
 #pragma unroll
@@ -65,121 +67,152 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const f
     }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(
+template <int BN, int BK>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ bias,
     float* __restrict__ C, int ldc, int tiles_n, int nk, int act, int epi, float alpha)
 {
+    constexpr int BM = GEMM_BM, NW = GEMM_WM * GEMM_WN;
+    constexpr int MI = BM / GEMM_WM / 32, NI = BN / GEMM_WN / 32;
+    constexpr int CH = BK / 4;                      // 16-B chunks per row
+    constexpr int RPI = 64 / CH;                    // rows per 1-KiB wave-instruction
+    constexpr int STAGE_BYTES = (BM + BN) * BK * 4;
+    constexpr int A_PER_WAVE = BM / RPI / NW, W_PER_WAVE = BN / RPI / NW;
+    constexpr int LOADS = A_PER_WAVE + W_PER_WAVE;  // LDS-DMA instructions per wave per stage
+    constexpr int TS = BK / 8;                      // 8-k sub-steps per stage
+    constexpr int SLOTS = TS * 4;                   // MFMA groups per stage
+    constexpr int EVERY = SLOTS / LOADS > 0 ? SLOTS / LOADS : 1;
+    constexpr int SW_SHIFT = (BK == 32) ? 1 : 2;    // 128-B rows: (row>>1)&7 ; 64-B rows: (row>>2)&3
+    constexpr int SW_MASK = CH - 1;
+    static_assert(LOADS <= SLOTS, "not enough MFMA groups to interleave the LDS-DMA issue");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous run
-    // of tiles, n fastest, so the blocks resident on one XCD share A panels and the whole of W in its L2.
-    const int nwg = gridDim.x;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7;
-    const int q = nwg >> 3, r8 = nwg & 7;
+    // of tiles, n fastest, so the blocks resident on one XCD share A panels and W in its L2.
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
     const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    const int tm = tile / tiles_n;
-    const int tn = tile - tm * tiles_n;
-    const int m0 = tm * GEMM_BM;
-    const int n0 = tn * GEMM_BN;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / GEMM_WN, wn = wave % GEMM_WN;
 
-    // per-lane source offsets for the 4 LDS-DMA pieces of each operand (8 rows x 128 B per wave-instruction)
-    const float* ga[4];
-    const float* gw[4];
+    const float* ga[A_PER_WAVE];
+    const float* gw[W_PER_WAVE];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (j * 4 + wave) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
+    for (int j = 0; j < A_PER_WAVE; ++j) {
+        const int r = (j * NW + wave) * RPI + lane / CH;
+        const int c = (lane % CH) ^ ((r >> SW_SHIFT) & SW_MASK);
         ga[j] = A + (size_t)(m0 + r) * lda + c * 4;
+    }
+#pragma unroll
+    for (int j = 0; j < W_PER_WAVE; ++j) {
+        const int r = (j * NW + wave) * RPI + lane / CH;
+        const int c = (lane % CH) ^ ((r >> SW_SHIFT) & SW_MASK);
         gw[j] = W + (size_t)(n0 + r) * ldw + c * 4;
     }
+    auto issue = [&](char* sbase, int k0, int l) {   // l-th LDS-DMA piece of a stage (wave-uniform LDS address)
+        if (l < A_PER_WAVE) __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(ga[l] + k0), AM_LDS_PTR(sbase + (l * NW + wave) * 1024), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(gw[l - A_PER_WAVE] + k0), AM_LDS_PTR(sbase + BM * BK * 4 + ((l - A_PER_WAVE) * NW + wave) * 1024), 16, 0, 0);
+    };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
 
-    auto stage = [&](int buf, int kt) {
-        char* base = smem + buf * GEMM_STAGE_BYTES;
-        const int k0 = kt * GEMM_BK;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rbase = (j * 4 + wave) * 8;  // wave-uniform
-            __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(ga[j] + k0), AM_LDS_PTR(base + rbase * 128), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(gw[j] + k0), AM_LDS_PTR(base + GEMM_BM * 128 + rbase * 128), 16, 0, 0);
-        }
-    };
-
     const int li = lane & 31, lh = lane >> 5;
-    // LDS float4 index of (row, chunk): row*8 + (chunk ^ ((row>>1)&7))
-    int arow[2], wrow[2], asw[2], wsw[2];
+    int aidx[MI], asw[MI], widx[NI], wsw[NI];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        arow[mi] = wm * 64 + mi * 32 + li;
-        asw[mi] = (arow[mi] >> 1) & 7;
-        wrow[mi] = wn * 64 + mi * 32 + li;
-        wsw[mi] = (wrow[mi] >> 1) & 7;
-    }
+    for (int mi = 0; mi < MI; ++mi) { const int r = wm * (BM / GEMM_WM) + mi * 32 + li; aidx[mi] = r * CH; asw[mi] = (r >> SW_SHIFT) & SW_MASK; }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) { const int r = wn * (BN / GEMM_WN) + ni * 32 + li; widx[ni] = r * CH; wsw[ni] = (r >> SW_SHIFT) & SW_MASK; }
 
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
+#pragma unroll
+    for (int l = 0; l < LOADS; ++l) issue(smem, 0, l);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) stage(buf ^ 1, kt + 1);
-        const f32x4* a4 = (const f32x4*)(smem + buf * GEMM_STAGE_BYTES);
-        const f32x4* w4 = (const f32x4*)(smem + buf * GEMM_STAGE_BYTES + GEMM_BM * 128);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage kt landed (this wave's pieces) ...
+        __builtin_amdgcn_s_barrier();                      // ... and everyone's; everyone is done reading stage kt-1
+        // prefetch stage kt+1 into the other buffer; the tail re-fetches the last stage into the idle buffer (never read)
+        const int kn = kt + 1 < nk ? kt + 1 : nk - 1;
+        char* sbase = smem + (buf ^ 1) * STAGE_BYTES;
+        const int k0 = kn * BK;
+        const f32x4* a4 = (const f32x4*)(smem + buf * STAGE_BYTES);
+        const f32x4* w4 = (const f32x4*)(smem + buf * STAGE_BYTES + BM * BK * 4);
+        f32x4 av[2][MI], bv[2][NI];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f32x4 av[2], bv[2];
+        for (int mi = 0; mi < MI; ++mi) av[0][mi] = a4[aidx[mi] + (lh ^ asw[mi])];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) av[mi] = a4[arow[mi] * 8 + ((2 * t + lh) ^ asw[mi])];
+        for (int ni = 0; ni < NI; ++ni) bv[0][ni] = w4[widx[ni] + (lh ^ wsw[ni])];
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) bv[ni] = w4[wrow[ni] * 8 + ((2 * t + lh) ^ wsw[ni])];
+        for (int t = 0; t < TS; ++t) {
+            if (t + 1 < TS) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int mi = 0; mi < MI; ++mi) av[(t + 1) & 1][mi] = a4[aidx[mi] + ((2 * (t + 1) + lh) ^ asw[mi])];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int ni = 0; ni < NI; ++ni) bv[(t + 1) & 1][ni] = w4[widx[ni] + ((2 * (t + 1) + lh) ^ wsw[ni])];
+            }
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][mi][j], bv[t & 1][ni][j], acc[mi][ni], 0, 0, 0);
+                const int slot = t * 4 + j;
+                if (slot % EVERY == 0 && slot / EVERY < LOADS) issue(sbase, k0, slot / EVERY);
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail prefetch before the wave ends
 
     // epilogue: one uniform dispatch on the mode, then straight-line code
-    const int erow = m0 + wm * 64 + 4 * lh, ecol = n0 + wn * 64 + li;
+    const int erow = m0 + wm * (BM / GEMM_WM) + 4 * lh, ecol = n0 + wn * (BN / GEMM_WN) + li;
     if (epi == EPI_ACT) {
-        if (act == 0) gemm_epilogue<0>(acc, bias, C, ldc, erow, ecol, alpha);
-        else if (act == 1) gemm_epilogue<1>(acc, bias, C, ldc, erow, ecol, alpha);
-        else gemm_epilogue<2>(acc, bias, C, ldc, erow, ecol, alpha);
-    } else if (epi == EPI_LINEAR) gemm_epilogue<3>(acc, bias, C, ldc, erow, ecol, alpha);
-    else if (epi == EPI_SCALE) gemm_epilogue<4>(acc, bias, C, ldc, erow, ecol, alpha);
-    else gemm_epilogue<5>(acc, bias, C, ldc, erow, ecol, alpha);
+        if (act == 0) gemm_epilogue<0, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
+        else if (act == 1) gemm_epilogue<1, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
+        else gemm_epilogue<2, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
+    } else if (epi == EPI_LINEAR) gemm_epilogue<3, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
+    else if (epi == EPI_SCALE) gemm_epilogue<4, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
+    else gemm_epilogue<5, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
 }
+
+constexpr int GEMM_LDS_256 = 2 * (GEMM_BM + 256) * 32 * 4;  // 128 KiB
+constexpr int GEMM_LDS_384 = 2 * (GEMM_BM + 384) * 16 * 4;  //  80 KiB
 
 hipError_t init_kernels()
 {
-    // per device: allow the GEMM's 64 KiB of dynamic LDS
-    return hipFuncSetAttribute((const void*)gemm_nt_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+    // per device: allow the GEMM's large dynamic LDS
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_f32_kernel<256, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_256);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)gemm_nt_f32_kernel<384, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_384);
+}
+
+int gemm_n_pad(int n)
+{
+    // 384-wide tiles when they waste fewer padded columns than 256-wide ones (1909 -> 1920 instead of 2048)
+    const int p256 = (n + 255) / 256 * 256, p384 = (n + 383) / 384 * 384;
+    return p384 < p256 ? p384 : p256;
 }
 
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g)
 {
-    const int tiles_m = g.M_pad / GEMM_BM, tiles_n = g.N_pad / GEMM_BN;
-    const int nk = g.K_pad / GEMM_BK;
-    hipLaunchKernelGGL(gemm_nt_f32_kernel, dim3(tiles_m * tiles_n), dim3(256), GEMM_LDS_BYTES, s,
-                       g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, nk, g.act, g.epi, g.alpha);
+    if (g.M_pad % GEMM_BM || g.K_pad % GEMM_BK || g.M_pad <= 0 || g.K_pad <= 0) return hipErrorInvalidValue;
+    const int tiles_m = g.M_pad / GEMM_BM;
+    if (g.N_pad % 256 == 0) {
+        const int tiles_n = g.N_pad / 256;
+        hipLaunchKernelGGL((gemm_nt_f32_kernel<256, 32>), dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), GEMM_LDS_256, s,
+                           g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 32, g.act, g.epi, g.alpha);
+    } else if (g.N_pad % 384 == 0) {
+        const int tiles_n = g.N_pad / 384;
+        hipLaunchKernelGGL((gemm_nt_f32_kernel<384, 16>), dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), GEMM_LDS_384, s,
+                           g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 16, g.act, g.epi, g.alpha);
+    } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
