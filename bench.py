@@ -84,16 +84,11 @@ def cpu_baseline(ft, params, layers, x, iv, seconds):
 
 def main():
     args = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # barrier + max-over-ranks only (gloo: no device tensors involved)
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    n_gpus = world if world > 1 else 1
-
+    from nnacousticmodeling_amd.dist_util import Ranks
     from nnacousticmodeling_amd.engine import Engine, Model, Pipeline
+    ranks = Ranks()  # RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env; gloo for barrier + max-over-ranks only
+    rank, local_rank, n_gpus = ranks.rank, ranks.local_rank, ranks.world
+
     ft, params, layers, x, iv, d_iv = make_workload(args.model, args.frames, rank)
     eng = Engine(local_rank)
     pipe = Pipeline(eng)
@@ -105,9 +100,7 @@ def main():
         pipe.ff_run()
     eng.synchronize()
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    barrier = ranks.barrier
 
     eng.profile(True)
     eng.profile_reset()
@@ -125,11 +118,7 @@ def main():
     dev_ms = eng.elapsed_ms(0, 1)
     prof = eng.profile_read()
     eng.profile(False)
-    if dist is not None:
-        import torch
-        t = torch.tensor([wall], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    wall = ranks.max_over_ranks(wall)
 
     if rank == 0:
         frames_total = args.frames * args.steps * n_gpus
@@ -156,9 +145,7 @@ def main():
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ft, params, layers, x, iv, args.cpu_seconds)
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,90 @@
+"""Posterior writer + scorer: drop-in for the reference's ``scripts/util/evaluateModelForTest.py`` (surface A).
+
+``evaluateModelTestTri`` keeps the reference's signature and side effects (evaluateModelForTest.py:36-133): per
+utterance ``lab/<utt>.lab`` in ``saveBin`` format holding ``y - ap`` re-normalised with ``y - logsum(y)``, one
+``lab/<test|dev>.scp`` line per utterance in list order, then the PhoneRecog subprocess and the PER computation.
+The network forward, prior subtraction and log-normalisation run on the GPU over the whole file at once (rows are
+independent, so batching per utterance as the reference does gives the same rows).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from .kw_io import saveBin
+from .networks import as_ensemble
+from .sharding import get_runner
+
+
+def compute_posteriors(model, data, offsets, ap=None, devices=(0,), rnn=False, frontend=None, ivectors=None):
+    """float32 ``[N, C]`` log-posteriors (minus priors, renormalised) for the whole file.
+
+    ``frontend=None``: ``data`` is what the reference passes -- already spliced / transformed / i-vector-extended
+    (evaluate.py:163-171) -- and is fed to the network as is.  ``frontend=(shifts, ft)``: ``data`` holds the raw frames
+    and the GPU applies splice + transform (+ ``ivectors`` appended after the transform) fused in one pass."""
+    runner = get_runner(devices)
+    ens = as_ensemble(model)
+    shifts, ft = ([0], None) if frontend is None else frontend
+    if rnn:
+        if len(list(shifts)) != 1:
+            raise ValueError("operands could not be broadcast together: recurrent networks take un-spliced frames")
+        return runner.forward_lstm(ens, data, offsets, ft=ft, ivectors=ivectors, timedelay=0, prior=ap)
+    return runner.forward_ff(ens, data, shifts=shifts, ft=ft, ivectors=ivectors, prior=ap)
+
+
+def write_posteriors(y, offsets, testList, labDirOut, testOrDev):
+    """``.lab`` per utterance + the ``.scp`` list, byte-compatible with the reference (evaluateModelForTest.py:43-45,
+    88-94, 113-117).  Returns the scp path."""
+    labDirOut = Path(labDirOut)
+    labDirOut.mkdir(exist_ok=True, parents=True)
+    scp = Path(labDirOut, testOrDev + ".scp")
+    with open(str(scp), "wt") as fscp:
+        for i, f in enumerate(testList):
+            f = f.strip()
+            labout = Path(labDirOut, f + ".lab")
+            saveBin(str(labout), y[offsets[i]:offsets[i + 1], :])
+            fscp.write(str(labout) + "\n")
+    return scp
+
+
+def evaluateModelTestTri(model, data, offsets, PIP, LMW, ap=None, GPUID=0, testOrDev="test", tmpDir="lab", uttlistdir=".",
+                         recogdir=".", progress=True, rnn=False, frontend=None, ivectors=None, run_decoder="auto"):
+    """Returns the PER (float); -1 when the utterance list and the offsets disagree, as the reference does.
+
+    Differences from the reference, all on the host side: ``GPUID`` may be a list of device ids (negative = CPU is
+    refused: no CPU fallback); ``frontend`` / ``ivectors`` select the fused on-GPU frontend (see
+    ``compute_posteriors``); ``run_decoder``: "auto" runs PhoneRecog only when the binary and ``kaldiTri1909.img``
+    exist under ``recogdir`` and otherwise stops after writing the posteriors, returning NaN."""
+    testList = open(uttlistdir + "/" + testOrDev + ".list").readlines()
+    if len(testList) != len(offsets) - 1:
+        print("Error: wrong number of utterances")
+        return -1
+    devices = list(GPUID) if isinstance(GPUID, (list, tuple)) else [GPUID]
+    if progress:
+        print("Calculating network outputs")
+    y = compute_posteriors(model, data, offsets, ap=ap, devices=devices, rnn=rnn, frontend=frontend, ivectors=ivectors)
+    if progress:
+        print("Writing output files")
+    labDirOut = Path(tmpDir)
+    scp = write_posteriors(y, np.asarray(offsets), testList, labDirOut, testOrDev)
+
+    recog = recogdir + "/PhoneRecog" + (".exe" if os.name == "nt" else "")
+    img = str(Path(recogdir, "kaldiTri1909.img"))
+    have_decoder = os.path.isfile(recog) and os.path.isfile(img)
+    if run_decoder == "auto" and not have_decoder:
+        print("PhoneRecog or kaldiTri1909.img not found under %s: posteriors written to %s, decoding skipped" % (recogdir, scp))
+        return float("nan")
+    if not run_decoder:
+        return float("nan")
+    from .scoring import computeWER, convert_results, loadMlf
+    result_txt = str(Path(labDirOut, "vysledek_" + testOrDev + ".txt"))
+    cmd = [recog, str(scp), img, result_txt, str(-abs(PIP)), str(LMW)]
+    subprocess.run(cmd, cwd=os.getcwd())
+    p39 = str(Path(labDirOut, "vysledek_" + testOrDev + "_p39.txt"))
+    convert_results(str(Path(recogdir, "phones.60-48-39.map")), result_txt, p39)
+    ref = loadMlf(str(Path(recogdir, testOrDev + "_ref.mlf")))
+    result = loadMlf(p39)
+    return computeWER(result, ref, True)

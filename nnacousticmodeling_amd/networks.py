@@ -1,0 +1,146 @@
+"""Host-side network descriptions mirroring the reference's model zoo for the in-scope networks.
+
+``get_nn`` / ``is_nn_recurrent`` follow scripts/common/chainer_networks.py:163-187; ``NNWithRPL`` follows
+scripts/common/evaluate.py:19-51; ``RPL4`` follows scripts/common/RPL.py:58-74.  The objects here hold host copies of
+the parameters only; all arithmetic runs on the GPU (``sharding.PosteriorRunner`` uploads them through the C ABI).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SUPPORTED = ("ff", "lstm")
+ALL_REFERENCE_NETWORKS = ("ff", "tdnn", "lstm", "zoneoutlstm", "zoneoutdropoutlstm", "peepholelstm", "gru", "mgrurelu", "mgrurelur")
+
+
+def is_nn_recurrent(n):
+    return n.endswith("lstm") or n.startswith("gru") or n.startswith("mgru")
+
+
+class NetworkSpec:
+    """An un-initialised network, as ``get_nn`` returns it; ``chainer_npz.load_npz`` fills the parameters."""
+
+    def __init__(self, network, layers, units, num_classes, activation="relu"):
+        self.network = network
+        self.layers = int(layers)
+        self.units = int(units)
+        self.num_classes = int(num_classes)
+        self.activation = activation
+        self.params = None
+        self.source = None
+
+    @property
+    def recurrent(self):
+        return is_nn_recurrent(self.network)
+
+    def reset_state(self):  # the device path keeps no state between calls
+        pass
+
+    def expected_keys(self):
+        keys = []
+        for l in range(self.layers):
+            if self.network == "ff":
+                keys += ["layer_%d/W" % l, "layer_%d/b" % l]
+            else:
+                keys += ["layer_%d/upward/W" % l, "layer_%d/upward/b" % l, "layer_%d/lateral/W" % l]
+        return keys + ["out/W", "out/b"]
+
+    def set_params(self, params, source=None):
+        """Shape checks equivalent to what ``load_npz`` enforces: biases and lateral weights are created with the
+        declared sizes (``L.Linear(None, n_units)``, ``L.LSTM(None, n_units)``), only input widths come from the file."""
+        missing = [k for k in self.expected_keys() if k not in params]
+        if missing:
+            raise KeyError("%s: missing parameter(s) %s for a %d-layer %s network" % (source, missing, self.layers, self.network))
+        p = {k: np.ascontiguousarray(params[k], dtype=np.float32) for k in self.expected_keys()}
+        for l in range(self.layers):
+            if self.network == "ff":
+                w, b = p["layer_%d/W" % l], p["layer_%d/b" % l]
+                want = self.units
+            else:
+                w, b = p["layer_%d/upward/W" % l], p["layer_%d/upward/b" % l]
+                want = 4 * self.units
+                lat = p["layer_%d/lateral/W" % l]
+                if lat.shape != (4 * self.units, self.units):
+                    raise ValueError("%s: layer_%d/lateral/W has shape %s, expected %s" % (source, l, lat.shape, (4 * self.units, self.units)))
+            if b.shape != (want,) or w.shape[0] != want:
+                raise ValueError("%s: layer %d holds %d outputs but --units says %d" % (source, l, b.shape[0], want))
+        if p["out/b"].shape != (self.num_classes,) or p["out/W"].shape[0] != self.num_classes:
+            raise ValueError("%s: output layer has %d classes, expected %d" % (source, p["out/b"].shape[0], self.num_classes))
+        self.params = p
+        self.source = source
+        return self
+
+    @property
+    def in_dim(self):
+        key = "layer_0/W" if self.network == "ff" else "layer_0/upward/W"
+        if self.layers == 0:
+            key = "out/W"
+        return int(self.params[key].shape[1])
+
+
+class RPL4Spec:
+    """RPL4 parameters W, b, lb, each [1, C] (RPL.py:58-66)."""
+
+    def __init__(self, num_classes):
+        self.num_classes = int(num_classes)
+        self.W = np.zeros((1, num_classes), dtype=np.float32)
+        self.b = np.zeros((1, num_classes), dtype=np.float32)
+        self.lb = np.full((1, num_classes), -20.0, dtype=np.float32)
+
+    def set_params(self, params, source=None):
+        for k in ("W", "b", "lb"):
+            if k not in params:
+                raise KeyError("%s: missing RPL parameter %r" % (source, k))
+            v = np.ascontiguousarray(params[k], dtype=np.float32).reshape(1, -1)
+            if v.shape[1] != self.num_classes:
+                raise ValueError("%s: RPL parameter %s has %d entries, expected %d" % (source, k, v.shape[1], self.num_classes))
+            setattr(self, k, v)
+        return self
+
+
+def get_nn(network, layers, units, num_classes, activation="relu", tdnn_ksize=None, dropout=(0,)):
+    """Same argument order as the reference ``get_nn``.  ``activation`` is a name (relu/sigmoid/tanh); dropout is
+    accepted and ignored (identity at inference, evaluate.py:94).  Networks outside the hot-path scope are refused."""
+    if network in SUPPORTED:
+        if activation not in ("relu", "sigmoid", "tanh"):
+            raise ValueError("Wrong activation function specified")
+        return NetworkSpec(network, layers, units[0] if isinstance(units, (list, tuple)) else units, num_classes, activation)
+    if network in ALL_REFERENCE_NETWORKS:
+        raise NotImplementedError("network %r exists in the reference but is outside the MI355X hot-path scope (ff, lstm)" % network)
+    raise ValueError("Wrong network type specified")
+
+
+class NNWithRPL:
+    """Ensemble wrapper with the semantics of the reference class of the same name (evaluate.py:19-51):
+    master only -> master(x); master + K folds -> (K*master + sum folds)/(2K) on raw logits; folds only -> mean of
+    logits; then the optional RPL4 layer."""
+
+    def __init__(self, master=None, folds=(), rpl=None):
+        self.master = master
+        self.folds = list(folds)
+        self.num_folds = len(self.folds)
+        self.rpl = rpl
+        if master is None and not self.folds:
+            raise ValueError("NNWithRPL needs a master network or at least one fold network")
+
+    def reset_state(self):
+        pass
+
+    def members(self):
+        return ([self.master] if self.master is not None else []) + self.folds
+
+    @property
+    def has_master(self):
+        return self.master is not None
+
+    @property
+    def recurrent(self):
+        return self.members()[0].recurrent
+
+    @property
+    def num_classes(self):
+        return self.members()[0].num_classes
+
+
+def as_ensemble(model):
+    """A bare NetworkSpec behaves like NNWithRPL(master=spec)."""
+    return model if isinstance(model, NNWithRPL) else NNWithRPL(master=model)

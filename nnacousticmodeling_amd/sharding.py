@@ -1,0 +1,219 @@
+"""Shard the posterior computation over the GPUs of one node and gather on the host.
+
+Frames (feed-forward) and utterances (recurrent) are independent, so the path shards with no collective
+(SURVEY.md 8e): contiguous frame ranges with a +-context read halo for ``ff`` -- the splice clamps only at the global
+ends of the file (reference kw_utils.py:29-33), never at shard or utterance boundaries -- and longest-first bins of
+whole utterances for ``lstm``.  One host thread drives each GPU through its own engine (ctypes releases the GIL);
+the gather is a plain copy into the single output array.
+"""
+from __future__ import annotations
+
+import threading
+
+import numpy as np
+
+from ._lib import AM_COMBINE_LOGITS, AM_COMBINE_LOGPOST
+from .networks import as_ensemble
+
+
+# ---------------------------------------------------------------------------------------------------
+# pure partitioning helpers
+# ---------------------------------------------------------------------------------------------------
+def ff_shards(n_frames, n_parts, context):
+    """Contiguous ranges [lo, hi) plus the halo rows that exist around them: [(lo, hi, halo_lo, halo_hi), ...].
+    Empty ranges are dropped."""
+    n_parts = max(1, min(int(n_parts), max(int(n_frames), 1)))
+    out = []
+    for g in range(n_parts):
+        lo = n_frames * g // n_parts
+        hi = n_frames * (g + 1) // n_parts
+        if hi > lo:
+            out.append((lo, hi, min(context, lo), min(context, n_frames - hi)))
+    return out
+
+
+def lstm_bins(offsets, n_parts):
+    """Greedy longest-first packing of utterances onto ``n_parts`` bins, balancing total frames.
+    -> list of utterance-index arrays (each in file order), empty bins dropped."""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    lens = np.diff(offsets)
+    n_parts = max(1, min(int(n_parts), max(len(lens), 1)))
+    order = np.argsort(-lens, kind="stable")
+    load = np.zeros(n_parts, dtype=np.int64)
+    bins = [[] for _ in range(n_parts)]
+    for u in order:
+        b = int(np.argmin(load))
+        bins[b].append(int(u))
+        load[b] += lens[u]
+    return [np.sort(np.asarray(b, dtype=np.int64)) for b in bins if b]
+
+
+def gather_utterances(x, offsets, utts):
+    """Rows of the utterances ``utts`` concatenated, plus their local offsets."""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    parts = [x[offsets[u]:offsets[u + 1]] for u in utts]
+    local = np.zeros(len(utts) + 1, dtype=np.int64)
+    local[1:] = np.cumsum([p.shape[0] for p in parts])
+    cat = np.concatenate(parts, axis=0) if parts else np.zeros((0, x.shape[1]), dtype=x.dtype)
+    return np.ascontiguousarray(cat), local
+
+
+# ---------------------------------------------------------------------------------------------------
+# runner
+# ---------------------------------------------------------------------------------------------------
+class _DeviceState:
+    def __init__(self, backend, device):
+        self.engine = backend.Engine(device)
+        self.models = {}
+        self.pipeline = backend.Pipeline(self.engine)
+
+
+class PosteriorRunner:
+    """Runs an ensemble (``NetworkSpec`` or ``NNWithRPL``) on one or more GPUs.
+
+    ``devices``: list of device ids.  ``backend``: module providing Engine/Model/Pipeline (default: the HIP engine;
+    the CPU-only test-suite injects a stand-in to exercise this host logic without a GPU)."""
+
+    def __init__(self, devices=(0,), backend=None):
+        if backend is None:
+            from . import engine as backend
+        self.backend = backend
+        self.devices = [int(d) for d in devices]
+        if not self.devices:
+            raise ValueError("no device given")
+        for d in self.devices:
+            if d < 0:
+                raise ValueError("negative GPU id (CPU execution) is not supported: this path has no CPU fallback")
+        self._state = {}
+        self._lock = threading.Lock()
+
+    def _dev(self, device):
+        with self._lock:
+            st = self._state.get(device)
+            if st is None:
+                st = self._state[device] = _DeviceState(self.backend, device)
+            return st
+
+    def _configure(self, st, ensemble, D, shifts, ft, d_iv, prior, combine, normalise):
+        members = []
+        for spec in ensemble.members():
+            key = id(spec)
+            m = st.models.get(key)
+            if m is None:
+                if spec.params is None:
+                    raise ValueError("network has no parameters loaded (chainer_npz.load_npz)")
+                m = st.models[key] = self.backend.Model(st.engine, spec.network, spec.layers, spec.params, spec.activation)
+            members.append(m)
+        p = st.pipeline
+        add, scale = (None, None) if ft is None else (ft["addShift"], ft["rescale"])
+        p.set_frontend(D, shifts, add, scale, d_iv)
+        p.set_members(members, has_master=ensemble.has_master and combine == AM_COMBINE_LOGITS, combine=combine)
+        rpl = ensemble.rpl
+        if rpl is not None:
+            p.set_rpl4(rpl.W, rpl.b, rpl.lb)
+        else:
+            p.set_rpl4(None, None, None)
+        p.set_prior(prior)
+        p.set_normalise(normalise)
+        return p
+
+    def _run_parallel(self, jobs):
+        """jobs: list of (device, callable).  One thread per job; first exception is re-raised."""
+        if len(jobs) == 1:
+            jobs[0][1]()
+            return
+        errors = []
+
+        def wrap(fn):
+            try:
+                fn()
+            except BaseException as exc:  # noqa: BLE001 - re-raised below
+                errors.append(exc)
+
+        threads = [threading.Thread(target=wrap, args=(fn,)) for _, fn in jobs]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+
+    # feed-forward ----------------------------------------------------------------------------------
+    def forward_ff(self, model, x, shifts=(0,), ft=None, ivectors=None, prior=None, combine=AM_COMBINE_LOGITS, normalise=True):
+        """x: [N, D] raw frames of the whole file.  Returns float32 [N, C] in file order."""
+        ens = as_ensemble(model)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n, D = x.shape
+        iv = None if ivectors is None else np.ascontiguousarray(ivectors, dtype=np.float32)
+        d_iv = 0 if iv is None else iv.shape[1]
+        shifts = [int(s) for s in shifts]
+        ctx = max(abs(s) for s in shifts)
+        y = np.empty((n, ens.num_classes), dtype=np.float32)
+        shards = ff_shards(n, len(self.devices), ctx)
+        jobs = []
+        for (lo, hi, h_lo, h_hi), dev in zip(shards, self.devices):
+            def job(lo=lo, hi=hi, h_lo=h_lo, h_hi=h_hi, dev=dev):
+                st = self._dev(dev)
+                p = self._configure(st, ens, D, shifts, ft, d_iv, prior, combine, normalise)
+                p.forward_ff(x[lo - h_lo:hi + h_hi], None if iv is None else iv[lo:hi], hi - lo, h_lo, h_hi, out=y[lo:hi])
+            jobs.append((dev, job))
+        if jobs:
+            self._run_parallel(jobs)
+        return y
+
+    # recurrent -------------------------------------------------------------------------------------
+    def forward_lstm(self, model, x, offsets, ft=None, ivectors=None, timedelay=0, prior=None, combine=AM_COMBINE_LOGITS, normalise=True):
+        """x: [N, D] frames of whole utterances delimited by ``offsets``.  Returns float32 [N, C] in file order."""
+        ens = as_ensemble(model)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        offsets = np.asarray(offsets, dtype=np.int64)
+        n, D = x.shape
+        iv = None if ivectors is None else np.ascontiguousarray(ivectors, dtype=np.float32)
+        d_iv = 0 if iv is None else iv.shape[1]
+        y = np.zeros((n, ens.num_classes), dtype=np.float32)
+        bins = lstm_bins(offsets, len(self.devices))
+        jobs = []
+        for utts, dev in zip(bins, self.devices):
+            def job(utts=utts, dev=dev):
+                st = self._dev(dev)
+                p = self._configure(st, ens, D, [0], ft, d_iv, prior, combine, normalise)
+                if len(bins) == 1:
+                    p.forward_lstm(x, offsets, iv, timedelay, out=y)
+                    return
+                xs, local = gather_utterances(x, offsets, utts)
+                ivs = None if iv is None else gather_utterances(iv, offsets, utts)[0]
+                ys = p.forward_lstm(xs, local, ivs, timedelay)
+                for j, u in enumerate(utts):
+                    y[offsets[u]:offsets[u + 1]] = ys[local[j]:local[j + 1]]
+            jobs.append((dev, job))
+        if jobs:
+            self._run_parallel(jobs)
+        return y
+
+    def close(self):
+        for st in self._state.values():
+            st.pipeline.close()
+            for m in st.models.values():
+                m.close()
+            st.engine.close()
+        self._state = {}
+
+
+_default_runners = {}
+
+
+def get_runner(devices):
+    """Process-wide cache of runners keyed by the device tuple (models stay resident across calls)."""
+    key = tuple(int(d) for d in devices)
+    r = _default_runners.get(key)
+    if r is None:
+        r = _default_runners[key] = PosteriorRunner(key)
+    return r
+
+
+def parse_devices(gpu, n_gpus=None):
+    """``--gpu G`` (reference: one device id) plus the extension ``--gpus N``: devices G..G+N-1."""
+    if gpu < 0:
+        raise SystemExit("--gpu %d: CPU execution is not supported by the MI355X engine (no CPU fallback)" % gpu)
+    n = 1 if not n_gpus else int(n_gpus)
+    return list(range(gpu, gpu + n))

@@ -91,6 +91,55 @@ def main():
         yy = yy - kw_utils.logsum(yy, axis=1)
         out["coef_%g" % coef] = yy
     np.savez(os.path.join(HERE, "prior_sub.npz"), y=y, **{k.replace(".", "p"): v for k, v in out.items()})
+    # 7. scoring chain: loadMlf / levenshtein_nist / computeWER / convert_results semantics
+    import json
+    import tempfile
+    import levenshtein  # reference scripts/util/levenshtein.py (numpy-only)
+    sys.path.insert(0, os.path.join(REF, "scripts", "util"))
+    shutil.copyfile(os.path.join(REF, "recog", "phones.60-48-39.map"), os.path.join(HERE, "phones.60-48-39.map"))
+    ref_mlf = kw_utils.loadMlf(os.path.join(REF, "recog", "test_ref.mlf"))
+    utts = sorted(ref_mlf.keys(), key=lambda u: ref_mlf[u][3])[:40]
+    phones = sorted({w for u in utts for w in ref_mlf[u][0]})
+    prng = np.random.default_rng(SEED + 7)
+    cases = []
+    for u in utts:
+        ref_words = list(ref_mlf[u][0])
+        hyp = []
+        for w in ref_words:
+            r = prng.random()
+            if r < 0.08:
+                continue                                   # deletion
+            if r < 0.18:
+                hyp.append(phones[prng.integers(len(phones))])  # substitution
+            else:
+                hyp.append(w)
+            if prng.random() < 0.07:
+                hyp.append("sil" if prng.random() < 0.5 else phones[prng.integers(len(phones))])  # insertion
+        if prng.random() < 0.3 and hyp and hyp[0] == "sil":
+            hyp = hyp[1:]                                  # optional leading silence dropped
+        if prng.random() < 0.2:
+            hyp = hyp[: max(1, len(hyp) // 2)]             # much shorter hypothesis -> flipped alignment
+        nist = [int(v) for v in levenshtein.levenshtein_nist(hyp, ref_words)]
+        plain = [int(v) for v in levenshtein.levenshtein2(hyp, ref_words)]
+        cases.append({"utt": u, "ref": ref_words, "hyp": hyp, "nist": nist, "plain": plain})
+    test_mlf = {c["utt"]: [c["hyp"], [], [], i] for i, c in enumerate(cases)}
+    sub_ref = {c["utt"]: ref_mlf[c["utt"]] for c in cases}
+    wer_nist = levenshtein.computeWER(test_mlf, sub_ref, True)
+    wer_plain = levenshtein.computeWER(test_mlf, sub_ref, False)
+    # loadMlf on a recogniser-style MLF with times, '#' comments, a blank line and trailing junk after '.'
+    rec_text = '#!MLF!#\n"lab\\\\FDHC0_SI1559.lab"\n0 300000 sil\n300000 900000 ax-h\n900000 1200000 el\n.\njunk after dot\n' \
+               '"*/MABC0_SX1.lab"\nsil\n\nhh\nzh\n.\n'
+    with tempfile.TemporaryDirectory() as td:
+        rec = os.path.join(td, "rec.mlf")
+        open(rec, "w").write(rec_text)
+        loaded = kw_utils.loadMlf(rec)
+        # convert_results lives in evaluateModelForTest.py (imports chainer) -> cannot be imported; its expected output is
+        # derived here from the map file by the documented rule and checked by hand (3 mapped phones below).
+    loaded_json = {k: [v[0], v[1], v[2], v[3]] for k, v in loaded.items()}
+    json.dump({"cases": cases, "wer_nist": wer_nist, "wer_plain": wer_plain, "n_ref_utts": len(ref_mlf),
+               "first_ref_utt": utts[0], "first_ref_words": ref_mlf[utts[0]][0], "rec_text": rec_text, "rec_loaded": loaded_json},
+              open(os.path.join(HERE, "scoring.json"), "w"), indent=0)
+    shutil.copyfile(os.path.join(REF, "recog", "test_ref.mlf"), os.path.join(HERE, "test_ref.mlf"))
     print("golden vectors written to", HERE)
 
 

@@ -1,0 +1,111 @@
+"""Host-side formats and parsers of the product package against the reference-generated golden vectors (CPU only)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from nnacousticmodeling_amd import chainer_npz, kaldi_ft, kw_io, networks, scoring
+from oracle import am_oracle as orc
+
+
+def test_feature_transform_parser_matches_reference(golden_dir, real_ft_path):
+    g = np.load(os.path.join(golden_dir, "ft_parse.npz"))
+    ft = kaldi_ft.loadKaldiFeatureTransform(real_ft_path)
+    assert ft["shape"] == [440, 40] and ft["shifts"] == list(range(-5, 6))
+    assert np.array_equal(ft["addShift"], g["addShift"]) and np.array_equal(ft["rescale"], g["rescale"])
+    kaldi_ft.select_centre_frame(ft)
+    assert ft["shifts"] == [0] and ft["shape"] == [40, 40]
+    assert np.array_equal(ft["addShift"], g["addShift"][200:240]) and np.array_equal(ft["rescale"], g["rescale"][200:240])
+
+
+def test_feature_transform_parser_rejects_garbage(tmp_path):
+    p = tmp_path / "bad.ft"
+    p.write_text("<Nnet>\n<Splice> 4 2\n[ -1 0 ]\n")
+    with pytest.raises(ValueError):
+        kaldi_ft.loadKaldiFeatureTransform(str(p))
+
+
+def test_savebin_bytes_match_reference(golden_dir, tmp_path):
+    g = np.load(os.path.join(golden_dir, "savebin.npz"))
+    kw_io.saveBin(str(tmp_path / "a.lab"), g["y2"])
+    kw_io.saveBin(str(tmp_path / "b.lab"), g["y1"])
+    assert (tmp_path / "a.lab").read_bytes() == open(os.path.join(golden_dir, "savebin_2d.bin"), "rb").read()
+    assert (tmp_path / "b.lab").read_bytes() == open(os.path.join(golden_dir, "savebin_1d.bin"), "rb").read()
+    assert np.array_equal(kw_io.loadBin(str(tmp_path / "a.lab")), g["back2"])
+    assert np.array_equal(kw_io.loadBin(str(tmp_path / "b.lab")), g["back1"])
+    empty = np.zeros((0, 1909), dtype=np.float32)  # zero-length utterance
+    kw_io.saveBin(str(tmp_path / "e.lab"), empty)
+    assert (tmp_path / "e.lab").read_bytes() == bytes([0, 0, 0, 0, 0x75, 0x07, 0, 0])
+
+
+def test_chainer_npz_roundtrip_and_shape_checks(tmp_path):
+    rng = np.random.default_rng(0)
+    p = orc.make_mlp_params(rng, 440, 64, 3, 1909)
+    path = tmp_path / "model"  # no .npz suffix, like train.py:393
+    chainer_npz.write_npz(path, p)
+    assert path.is_file() and not (tmp_path / "model.npz").exists()
+    with np.load(str(path)) as z:
+        assert sorted(z.files) == sorted("predictor/" + k for k in p)
+    spec = chainer_npz.load_npz(path, networks.get_nn("ff", 3, [64], 1909, "relu", [5], [0.2]))
+    assert spec.in_dim == 440 and all(np.array_equal(spec.params[k], p[k]) for k in p)
+    with pytest.raises(ValueError):  # --units disagrees with the stored bias
+        chainer_npz.load_npz(path, networks.get_nn("ff", 3, [128], 1909))
+    with pytest.raises(KeyError):    # --layers disagrees
+        chainer_npz.load_npz(path, networks.get_nn("ff", 4, [64], 1909))
+    with pytest.raises(ValueError):  # monophone head requested, file is triphone
+        chainer_npz.load_npz(path, networks.get_nn("ff", 3, [64], 39))
+    lp = orc.make_lstm_params(rng, 40, 32, 2, 1909)
+    chainer_npz.write_npz(tmp_path / "fold_0.npz", lp)
+    ls = chainer_npz.load_npz(tmp_path / "fold_0.npz", networks.get_nn("lstm", 2, [32], 1909))
+    assert ls.recurrent and ls.in_dim == 40
+    # oracle reader/writer agree with the product's
+    orc.save_chainer_npz(str(tmp_path / "o"), p)
+    assert all(np.array_equal(chainer_npz.read_npz(tmp_path / "o")[k], p[k]) for k in p)
+    assert all(np.array_equal(orc.load_chainer_npz(str(path))[k], p[k]) for k in p)
+
+
+def test_get_nn_scope():
+    assert networks.is_nn_recurrent("lstm") and networks.is_nn_recurrent("zoneoutlstm") and networks.is_nn_recurrent("gru")
+    assert networks.is_nn_recurrent("mgrurelu") and not networks.is_nn_recurrent("ff") and not networks.is_nn_recurrent("tdnn")
+    with pytest.raises(NotImplementedError):
+        networks.get_nn("gru", 2, [64], 1909)
+    with pytest.raises(ValueError):
+        networks.get_nn("nope", 2, [64], 1909)
+    with pytest.raises(ValueError):
+        networks.get_nn("ff", 2, [64], 1909, "swish")
+
+
+def test_scoring_matches_reference(golden_dir, tmp_path):
+    g = json.load(open(os.path.join(golden_dir, "scoring.json")))
+    for c in g["cases"]:
+        assert list(scoring.levenshtein_nist(c["hyp"], c["ref"])) == c["nist"], c["utt"]
+        assert list(scoring.levenshtein2(c["hyp"], c["ref"])) == c["plain"], c["utt"]
+    ref = scoring.loadMlf(os.path.join(golden_dir, "test_ref.mlf"))
+    assert len(ref) == g["n_ref_utts"] == 192
+    assert ref[g["first_ref_utt"]][0] == g["first_ref_words"] and ref[g["first_ref_utt"]][3] == 0
+    test = {c["utt"]: [c["hyp"], [], [], i] for i, c in enumerate(g["cases"])}
+    sub = {c["utt"]: ref[c["utt"]] for c in g["cases"]}
+    assert scoring.computeWER(test, sub, True) == pytest.approx(g["wer_nist"], abs=1e-12)
+    assert scoring.computeWER(test, sub, False) == pytest.approx(g["wer_plain"], abs=1e-12)
+    # MLF reader quirks: timed labels, blank line -> empty word, lines after '.' ignored, "*/" prefix dropped
+    rec = tmp_path / "rec.mlf"
+    rec.write_text(g["rec_text"])
+    got = scoring.loadMlf(str(rec))
+    assert {k: list(v) for k, v in got.items()} == g["rec_loaded"]
+    # identical hypothesis -> 0 % ; an optional sil costs nothing
+    assert scoring.computeWER(sub, sub, True) == 0.0
+    assert scoring.levenshtein_nist(["a", "b"], ["sil", "a", "b", "sil"])[2:] == (0, 0, 0)
+
+
+def test_convert_results_phone_map(golden_dir, tmp_path):
+    """convert_results (evaluateModelForTest.py:13-34) cannot be imported from the reference (chainer import at module
+    top), so this checks the documented rule on the real 60-48-39 map: last token mapped via column 2 -> column 3."""
+    rec = tmp_path / "vysledek_test.txt"
+    rec.write_text('#!MLF!#\n"lab\\FDHC0_SI1559.lab"\n0 300000 sil\n300000 900000 ao\n900000 1200000 zh\n.\n')
+    out = tmp_path / "p39.txt"
+    scoring.convert_results(os.path.join(golden_dir, "phones.60-48-39.map"), str(rec), str(out))
+    lines = out.read_text().split("\n")
+    assert lines[0] == "#!MLF!#" and lines[1] == '"lab/FDHC0_SI1559.rec"'
+    assert lines[2] == "0 300000 sil" and lines[3] == "300000 900000 aa" and lines[4] == "900000 1200000 sh" and lines[5] == "."
+    assert scoring.loadMlf(str(out))["lab/FDHC0_SI1559"][0] == ["sil", "aa", "sh"]

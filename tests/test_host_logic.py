@@ -1,0 +1,233 @@
+"""Host logic on CPU: sharding, host-side gather and the two drop-in CLIs, with the oracle-backed stand-in backend
+(tests/fake_backend.py) injected where the product would drive the GPU.  The product itself has no CPU path."""
+import os
+
+import numpy as np
+import pytest
+
+from nnacousticmodeling_amd import chainer_npz, evaluate, kw_io, networks, predict_folds, sharding
+from nnacousticmodeling_amd.evaluate_model_for_test import evaluateModelTestTri
+from oracle import am_oracle as orc
+from tests import fake_backend
+
+
+@pytest.fixture()
+def fake_runners(monkeypatch):
+    """Route get_runner() to oracle-backed runners for any device tuple."""
+    cache = {}
+
+    def get(devices):
+        key = tuple(devices)
+        if key not in cache:
+            cache[key] = sharding.PosteriorRunner(key, backend=fake_backend)
+        return cache[key]
+
+    monkeypatch.setattr(sharding, "get_runner", get)
+    monkeypatch.setattr(predict_folds, "get_runner", get)
+    import nnacousticmodeling_amd.evaluate_model_for_test as emt
+    monkeypatch.setattr(emt, "get_runner", get)
+    return cache
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_ff_shards_cover_and_halo():
+    for n, parts, ctx in [(1000, 8, 5), (7, 8, 5), (57919, 8, 5), (196608, 3, 0), (1, 1, 5), (10, 4, 20)]:
+        sh = sharding.ff_shards(n, parts, ctx)
+        assert sh[0][0] == 0 and sh[-1][1] == n
+        for (lo, hi, hl, hh), nxt in zip(sh, sh[1:] + [None]):
+            assert hi > lo and hl == min(ctx, lo) and hh == min(ctx, n - hi)
+            if nxt:
+                assert nxt[0] == hi
+        assert len(sh) <= parts
+    assert sharding.ff_shards(0, 4, 5) == []
+
+
+def test_lstm_bins_balance_and_cover():
+    rng = np.random.default_rng(1)
+    off = orc.make_offsets(rng, 192, 57919)
+    for parts in (1, 2, 8):
+        bins = sharding.lstm_bins(off, parts)
+        allu = np.sort(np.concatenate(bins))
+        assert np.array_equal(allu, np.arange(192))
+        loads = [int(np.diff(off)[b].sum()) for b in bins]
+        assert max(loads) - min(loads) <= np.diff(off).max()
+    assert len(sharding.lstm_bins(np.array([0, 5, 9]), 8)) == 2  # more GPUs than utterances
+    x = np.arange(18, dtype=np.float32).reshape(9, 2)
+    xs, local = sharding.gather_utterances(x, np.array([0, 5, 9]), [1])
+    assert np.array_equal(xs, x[5:9]) and list(local) == [0, 4]
+
+
+def test_runner_refuses_cpu():
+    with pytest.raises(ValueError):
+        sharding.PosteriorRunner([-1], backend=fake_backend)
+    with pytest.raises(SystemExit):
+        sharding.parse_devices(-1)
+    assert sharding.parse_devices(2, 3) == [2, 3, 4]
+
+
+@pytest.mark.parametrize("n_dev", [1, 3, 8])
+def test_sharded_ff_equals_whole_file_oracle(real_ft_path, n_dev):
+    rng = np.random.default_rng(2)
+    ft = orc.load_kaldi_feature_transform(real_ft_path)
+    params = orc.make_mlp_params(rng, 440, 48, 2, 39)
+    x = rng.standard_normal((501, 40)).astype(np.float32)
+    spec = networks.get_nn("ff", 2, [48], 39).set_params(params)
+    runner = sharding.PosteriorRunner(range(n_dev), backend=fake_backend)
+    got = runner.forward_ff(spec, x, shifts=range(-5, 6), ft=ft)
+    want = orc.predict(orc.MLP(params, 2), x, None, False, 11, 0, ft)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) < 1e-5  # BLAS batching differs between shards; splice/halo errors would be O(1)
+
+
+@pytest.mark.parametrize("n_dev,timedelay", [(1, 0), (4, 0), (3, 2)])
+def test_sharded_lstm_equals_whole_file_oracle(real_ft_path, n_dev, timedelay):
+    rng = np.random.default_rng(3)
+    ft = orc.centre_frame_transform(orc.load_kaldi_feature_transform(real_ft_path))
+    params = orc.make_lstm_params(rng, 40, 16, 2, 39)
+    off = orc.make_offsets(rng, 7, 90, lo=4, hi=30)
+    x = rng.standard_normal((90, 40)).astype(np.float32)
+    spec = networks.get_nn("lstm", 2, [16], 39).set_params(params)
+    runner = sharding.PosteriorRunner(range(n_dev), backend=fake_backend)
+    got = runner.forward_lstm(spec, x, off, ft=ft, timedelay=timedelay)
+    want = orc.predict(orc.LSTM(params, 2), x, off, True, 1, timedelay, ft)
+    assert np.max(np.abs(got - want)) < 1e-5
+    if timedelay:
+        for u in range(7):  # reference quirk: the last `timedelay` output frames of every utterance are zero
+            assert np.all(got[off[u + 1] - timedelay:off[u + 1]] == 0)
+
+
+# ---------------------------------------------------------------------------------------------------
+def _write_ft(path, real_ft_path):
+    with open(real_ft_path) as f, open(path, "w") as g:
+        g.write(f.read())
+
+
+def test_predict_folds_cli_per_fold_and_dev(tmp_path, fake_runners, real_ft_path):
+    rng = np.random.default_rng(4)
+    data_dir, fold_dir, model_dir, out_dir = (tmp_path / d for d in ("data", "folds", "models", "out"))
+    for d in (data_dir, fold_dir, model_dir):
+        d.mkdir()
+    _write_ft(data_dir / "final.feature_transform", real_ft_path)
+    ft = orc.load_kaldi_feature_transform(real_ft_path)
+    plist = [orc.make_mlp_params(rng, 440, 32, 2, 1909) for _ in range(3)]
+    xs = [rng.standard_normal((150 + 10 * k, 40)).astype(np.float32) for k in range(3)]
+    for k in range(3):
+        chainer_npz.write_npz(model_dir / ("fold_%d.npz" % k), plist[k])
+        np.save(fold_dir / ("data_%d.npy" % k), xs[k])
+    dev = rng.standard_normal((200, 40)).astype(np.float32)
+    np.save(data_dir / "data_dev.npy", dev)
+    common = ["-n", "ff", "-l", 2, "-u", 32, "-d", 0.2, "--splice", 5, "--tri", "--ft", "final.feature_transform", "--data-dir", data_dir,
+              "--fold-model-dir", model_dir, "--fold-output-dir", out_dir, "--no-progress", "--gpus", 2]
+    predict_folds.main(common + ["--fold-data-dir", fold_dir])
+    for k in range(3):
+        got = np.load(out_dir / ("data_%d.npy" % k))
+        want = orc.predict(orc.MLP(plist[k], 2), xs[k], None, False, 11, 0, ft)
+        assert got.dtype == np.float32 and got.shape == (xs[k].shape[0], 1909)
+        assert np.max(np.abs(got - want)) < 1e-5
+    assert not (out_dir / "data_3.npy").exists()
+    predict_folds.main(common + ["--fold-output-dev", "data_dev.npy"])
+    got = np.load(out_dir / "data_dev.npy")
+    want = orc.fold_average_dev([orc.MLP(p, 2) for p in plist], dev, None, False, 11, 0, ft)
+    assert np.max(np.abs(got - want)) < 1e-5
+    # no fold networks -> exit(2) like the reference
+    with pytest.raises(SystemExit) as ei:
+        predict_folds.main(common + ["--fold-data-dir", fold_dir, "--fold-model-dir", tmp_path / "nowhere"])
+    assert ei.value.code == 2
+
+
+def test_predict_folds_cli_lstm_timedelay(tmp_path, fake_runners, real_ft_path):
+    rng = np.random.default_rng(5)
+    data_dir, model_dir, out_dir = (tmp_path / d for d in ("data", "models", "out"))
+    data_dir.mkdir(), model_dir.mkdir()
+    _write_ft(data_dir / "final.feature_transform", real_ft_path)
+    ft = orc.centre_frame_transform(orc.load_kaldi_feature_transform(real_ft_path))
+    params = orc.make_lstm_params(rng, 40, 16, 2, 39)
+    chainer_npz.write_npz(model_dir / "fold_0.npz", params)
+    off = orc.make_offsets(rng, 5, 60, lo=4, hi=25)
+    x = rng.standard_normal((60, 40)).astype(np.float32)
+    np.save(data_dir / "data_0.npy", x)
+    np.save(data_dir / "offsets_0.npy", off.astype(np.int32))  # fold offsets are int32 (generate_folds.py:101)
+    predict_folds.main(["-n", "lstm", "-l", 2, "-u", 16, "-d", 0.2, "--timedelay", 3, "--ft", "final.feature_transform", "--data-dir", data_dir,
+                        "--fold-data-dir", data_dir, "--fold-model-dir", model_dir, "--fold-output-dir", out_dir, "--no-progress"])
+    got = np.load(out_dir / "data_0.npy")
+    want = orc.predict(orc.LSTM(params, 2), x, off, True, 1, 3, ft)
+    assert got.shape == (60, 39) and np.max(np.abs(got - want)) < 1e-5
+
+
+def _eval_dirs(tmp_path, real_ft_path, real_priors, n_utts, n_frames, rng):
+    data_dir, recog_dir, lab_dir = tmp_path / "data", tmp_path / "recog", tmp_path / "lab"
+    data_dir.mkdir(), recog_dir.mkdir()
+    _write_ft(data_dir / "final.feature_transform", real_ft_path)
+    np.save(recog_dir / "log_ap_Kaldi1909.npy", real_priors)
+    off = orc.make_offsets(rng, n_utts, n_frames, lo=5, hi=60)
+    x = rng.standard_normal((n_frames, 40)).astype(np.float32)
+    np.save(data_dir / "data_test.npy", x)
+    np.save(data_dir / "offsets_test.npy", off)
+    names = ["DR%d_SPK%d_SX%d" % (u % 8, u, 100 + u) for u in range(n_utts)]
+    (data_dir / "test.list").write_text("".join(n + "\n" for n in names))
+    return data_dir, recog_dir, lab_dir, off, x, names
+
+
+def test_evaluate_cli_ff_ensemble_writes_reference_files(tmp_path, fake_runners, real_ft_path, real_priors):
+    rng = np.random.default_rng(6)
+    data_dir, recog_dir, lab_dir, off, x, names = _eval_dirs(tmp_path, real_ft_path, real_priors, 6, 180, rng)
+    ft = orc.load_kaldi_feature_transform(real_ft_path)
+    fold_dir = tmp_path / "fold_models"
+    fold_dir.mkdir()
+    master = orc.make_mlp_params(rng, 440, 32, 2, 1909)
+    folds = [orc.make_mlp_params(rng, 440, 32, 2, 1909) for _ in range(2)]
+    chainer_npz.write_npz(tmp_path / "model", master)
+    for k, p in enumerate(folds):
+        chainer_npz.write_npz(fold_dir / ("fold_%d.npz" % k), p)
+    rpl = {"W": 0.05 * rng.standard_normal((1, 1909)).astype(np.float32), "b": 0.1 * rng.standard_normal((1, 1909)).astype(np.float32),
+           "lb": np.full((1, 1909), -20, np.float32)}
+    chainer_npz.write_npz(tmp_path / "rpl_model", rpl)
+    per = evaluate.main(["-n", "ff", "-l", 2, "-u", 32, "-d", 0.2, "--splice", 5, "--tri", "--data-dir", data_dir, "--offset-dir", data_dir,
+                         "--utt-list-dir", data_dir, "--recog-dir", recog_dir, "--rpl", "--master-network", tmp_path / "model",
+                         "--fold-model-dir", fold_dir, "--rpl-model", tmp_path / "rpl_model", "--ap-coef", 0.5, "--tmp-dir", lab_dir,
+                         "--no-progress", "--gpus", 2])
+    assert np.isnan(per)  # no PhoneRecog / kaldiTri1909.img here: posteriors written, decoding skipped
+    data = orc.evaluate_frontend(x, 5, ft)
+    omodel = orc.NNWithRPL(orc.MLP(master, 2), [orc.MLP(p, 2) for p in folds], orc.RPL4(rpl))
+    want = orc.evaluate_posteriors(omodel, data, off, ap=(0.5 * real_priors).astype(np.float32))
+    scp = (lab_dir / "test.scp").read_text().split("\n")
+    assert scp[-1] == "" and len(scp) == 7
+    for u, name in enumerate(names):
+        path = lab_dir / (name + ".lab")
+        assert scp[u] == str(path)
+        raw = path.read_bytes()
+        assert np.array_equal(np.frombuffer(raw[:8], dtype=np.uint32), [off[u + 1] - off[u], 1909])
+        got = kw_io.loadBin(str(path))
+        assert np.max(np.abs(got - want[u])) < 1e-5
+        assert np.array_equal(got, orc.load_bin(str(path)))
+
+
+def test_evaluate_function_contract_pretransformed_data_and_lstm(tmp_path, fake_runners, real_ft_path, real_priors):
+    """evaluateModelTestTri(model, data, ...) with `data` already spliced/transformed, as the reference passes it."""
+    rng = np.random.default_rng(7)
+    data_dir, recog_dir, lab_dir, off, x, names = _eval_dirs(tmp_path, real_ft_path, real_priors, 5, 120, rng)
+    ft = orc.centre_frame_transform(orc.load_kaldi_feature_transform(real_ft_path))
+    params = orc.make_lstm_params(rng, 40, 16, 2, 1909)
+    spec = networks.get_nn("lstm", 2, [16], 1909).set_params(params)
+    data = orc.evaluate_frontend(x, 0, ft)
+    per = evaluateModelTestTri(spec, data, off, 20, 1, ap=real_priors, GPUID=0, testOrDev="test", tmpDir=str(lab_dir),
+                               uttlistdir=str(data_dir), recogdir=str(recog_dir), progress=False, rnn=True)
+    assert np.isnan(per)
+    want = orc.evaluate_posteriors(orc.LSTM(params, 2), data, off, ap=real_priors, rnn=True)
+    for u, name in enumerate(names):
+        assert np.max(np.abs(kw_io.loadBin(str(lab_dir / (name + ".lab"))) - want[u])) < 1e-5
+    # utterance list / offsets mismatch -> -1, nothing computed (evaluateModelForTest.py:39-41)
+    assert evaluateModelTestTri(spec, data, off[:-1], 20, 1, ap=real_priors, GPUID=0, tmpDir=str(lab_dir), uttlistdir=str(data_dir),
+                                recogdir=str(recog_dir), progress=False, rnn=True) == -1
+
+
+def test_evaluate_cli_refuses_monophones_and_bad_activation(tmp_path, fake_runners, real_ft_path, real_priors, capsys):
+    rng = np.random.default_rng(8)
+    data_dir, recog_dir, lab_dir, off, x, names = _eval_dirs(tmp_path, real_ft_path, real_priors, 2, 40, rng)
+    chainer_npz.write_npz(tmp_path / "m", orc.make_mlp_params(rng, 440, 16, 1, 39))
+    base = ["-n", "ff", "-l", 1, "-u", 16, "--splice", 5, "--data-dir", data_dir, "--offset-dir", data_dir, "--utt-list-dir", data_dir,
+            "--recog-dir", recog_dir, "-m", tmp_path / "m", "--tmp-dir", lab_dir]
+    assert evaluate.main(base) is None
+    assert "Monophones not implemented" in capsys.readouterr().out
+    assert evaluate.main(base + ["-a", "swish"]) is None
+    assert "Wrong activation function specified" in capsys.readouterr().out
