@@ -116,6 +116,16 @@ struct am_pipeline {
     std::vector<int> n_active;
     int64_t n_packed = 0;
     int n_slots = 0;
+    // the recurrent launch sequence (thousands of ~2 us kernels) is replayed from a hipGraph from the 2nd run on
+    int lstm_runs = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    void drop_graph()
+    {
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        graph_exec = nullptr; graph = nullptr; lstm_runs = 0;
+    }
 };
 
 static constexpr int64_t FF_CHUNK_ROWS = 1 << 18;
@@ -289,7 +299,7 @@ static int upload(am_engine* e, DevBuf& d, const std::vector<float>& h)
     return AM_OK;
 }
 
-// destination row of (unit u, gate k) in the gate-tiled layout used by lstm_step_kernel
+// destination row of (unit u, gate k) in the gate-tiled layout used by lstm_wavefront_kernel
 static inline int gate_tiled_row(int u, int k) { return (u / 16) * 64 + k * 16 + (u % 16); }
 
 extern "C" int am_model_create(am_engine* e, int kind, int n_layers, int activation, const int* in_dims, const int* out_dims,
@@ -302,6 +312,10 @@ extern "C" int am_model_create(am_engine* e, int kind, int n_layers, int activat
     if (n_layers < 0 || n_layers > 64) return fail(AM_EINVAL, "am_model_create: bad layer count %d", n_layers);
     if (kind == AM_NET_FF && (activation < AM_ACT_RELU || activation > AM_ACT_TANH)) return fail(AM_EINVAL, "Wrong activation function specified");
     if (kind == AM_NET_LSTM && (!W_lat || n_layers < 1)) return fail(AM_EINVAL, "am_model_create: LSTM needs lateral weights and >= 1 layer");
+    if (kind == AM_NET_LSTM && n_layers > LSTM_MAX_LAYERS) return fail(AM_EINVAL, "am_model_create: at most %d LSTM layers are supported", LSTM_MAX_LAYERS);
+    if (kind == AM_NET_LSTM)
+        for (int l = 1; l < n_layers; ++l)
+            if (out_dims[l] != out_dims[0]) return fail(AM_EINVAL, "am_model_create: all LSTM layers must have the same number of units (chainer_networks.py:44-52)");
     for (int l = 0; l <= n_layers; ++l) {
         if (!W[l] || !b[l] || in_dims[l] <= 0 || out_dims[l] <= 0) return fail(AM_EINVAL, "am_model_create: layer %d has a NULL/empty parameter", l);
         if (kind == AM_NET_LSTM && l < n_layers && (out_dims[l] % 4 != 0 || !W_lat[l])) return fail(AM_EINVAL, "am_model_create: LSTM layer %d malformed", l);
@@ -327,7 +341,7 @@ extern "C" int am_model_create(am_engine* e, int kind, int n_layers, int activat
         else Ly.in_pad = (kind == AM_NET_LSTM) ? m->L[l - 1].U_pad : m->L[l - 1].out_pad;
         if (lstm_layer) {
             Ly.U = Ly.out / 4;
-            Ly.U_pad = (int)round_up(Ly.U, 64);  // 4*U_pad is then a multiple of 256 (GEMM tile) and U_pad of 16 (step tile)
+            Ly.U_pad = (int)round_up(Ly.U, 128);  // multiple of the step kernel's k batch; 4*U_pad is then a GEMM tile multiple
             Ly.out_pad = 4 * Ly.U_pad;
             std::vector<float> w((size_t)Ly.out_pad * Ly.in_pad, 0.f), bb(Ly.out_pad, 0.f), wl((size_t)Ly.out_pad * Ly.U_pad, 0.f);
             for (int u = 0; u < Ly.U; ++u)
@@ -382,6 +396,7 @@ extern "C" int am_pipeline_destroy(am_pipeline* p)
     if (!p) return AM_OK;
     (void)hipSetDevice(p->e->device);
     (void)hipStreamSynchronize(p->e->stream);
+    p->drop_graph();
     for (DevBuf* d : {&p->d_shifts, &p->d_add, &p->d_scale, &p->d_rplw, &p->d_rplb, &p->d_rpllb, &p->d_prior, &p->d_x, &p->d_ivec, &p->d_in,
                       &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_src, &p->d_dst, &p->d_G, &p->d_H0, &p->d_H1, &p->d_c})
         d->release();
@@ -406,7 +421,7 @@ extern "C" int am_pipeline_set_frontend(am_pipeline* p, int D, int n_shifts, con
         HIP_TRY(hipMemcpyAsync(p->d_scale.p, rescale, bytes, hipMemcpyHostToDevice, p->e->stream));
     }
     HIP_TRY(hipStreamSynchronize(p->e->stream));
-    p->mode = 0;
+    p->mode = 0; p->drop_graph();
     return AM_OK;
 }
 
@@ -424,7 +439,7 @@ extern "C" int am_pipeline_set_members(am_pipeline* p, int n_members, am_model* 
     p->members.assign(members, members + n_members);
     p->has_master = has_master ? 1 : 0;
     p->combine = combine;
-    p->mode = 0;
+    p->mode = 0; p->drop_graph();
     return AM_OK;
 }
 
@@ -439,7 +454,7 @@ static int set_vec(am_pipeline* p, DevBuf& d, const float* src, int c)
 extern "C" int am_pipeline_set_rpl4(am_pipeline* p, const float* W, const float* b, const float* lb)
 {
     if (!p) return fail(AM_EINVAL, "pipeline is NULL");
-    if (!W && !b && !lb) { p->has_rpl = false; return AM_OK; }
+    if (!W && !b && !lb) { p->has_rpl = false; p->drop_graph(); return AM_OK; }
     if (!W || !b || !lb) return fail(AM_EINVAL, "am_pipeline_set_rpl4: W, b, lb must all be given");
     if (p->members.empty()) return fail(AM_EINVAL, "am_pipeline_set_rpl4: set the members first");
     HIP_TRY(hipSetDevice(p->e->device));
@@ -448,26 +463,26 @@ extern "C" int am_pipeline_set_rpl4(am_pipeline* p, const float* W, const float*
     AM_TRY(set_vec(p, p->d_rplw, W, c));
     AM_TRY(set_vec(p, p->d_rplb, b, c));
     AM_TRY(set_vec(p, p->d_rpllb, lb, c));
-    p->has_rpl = true;
+    p->has_rpl = true; p->drop_graph();
     return AM_OK;
 }
 
 extern "C" int am_pipeline_set_prior(am_pipeline* p, const float* ap)
 {
     if (!p) return fail(AM_EINVAL, "pipeline is NULL");
-    if (!ap) { p->has_prior = false; return AM_OK; }
+    if (!ap) { p->has_prior = false; p->drop_graph(); return AM_OK; }
     if (p->members.empty()) return fail(AM_EINVAL, "am_pipeline_set_prior: set the members first");
     HIP_TRY(hipSetDevice(p->e->device));
     HIP_TRY(hipStreamSynchronize(p->e->stream));
     AM_TRY(set_vec(p, p->d_prior, ap, p->members[0]->C));
-    p->has_prior = true;
+    p->has_prior = true; p->drop_graph();
     return AM_OK;
 }
 
 extern "C" int am_pipeline_set_normalise(am_pipeline* p, int on)
 {
     if (!p) return fail(AM_EINVAL, "pipeline is NULL");
-    p->normalise = on ? 1 : 0;
+    p->normalise = on ? 1 : 0; p->drop_graph();
     return AM_OK;
 }
 
@@ -695,21 +710,24 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
     HIP_TRY(hipMemcpyAsync(p->d_dst.p, dst.data(), sizeof(int) * dst.size(), hipMemcpyHostToDevice, e->stream));
     AM_TRY(p->d_in.ensure(sizeof(float) * rows_alloc * m0->in_pad));
     AM_TRY(p->d_G.ensure(sizeof(float) * rows_alloc * gw));
-    AM_TRY(p->d_H0.ensure(sizeof(float) * rows_alloc * upad));
-    AM_TRY(p->d_H1.ensure(sizeof(float) * rows_alloc * upad));
-    HIP_TRY(hipMemsetAsync(p->d_H0.p, 0, sizeof(float) * rows_alloc * upad, e->stream));
-    HIP_TRY(hipMemsetAsync(p->d_H1.p, 0, sizeof(float) * rows_alloc * upad, e->stream));
+    int max_layers = 0;
+    for (auto* m : p->members) max_layers = std::max(max_layers, m->n_layers);
+    AM_TRY(p->d_H0.ensure(sizeof(float) * rows_alloc * upad * max_layers));      // one H plane per layer
+    HIP_TRY(hipMemsetAsync(p->d_H0.p, 0, sizeof(float) * rows_alloc * upad * max_layers, e->stream));
     HIP_TRY(hipMemsetAsync(p->d_G.p, 0, sizeof(float) * rows_alloc * gw, e->stream));
-    AM_TRY(p->d_c.ensure(sizeof(float) * (round_up(std::max(n_utts, 1), 16)) * upad));
+    AM_TRY(p->d_c.ensure(sizeof(float) * (round_up(std::max(n_utts, 1), 16)) * upad * max_layers));
     AM_TRY(p->d_acc.ensure(sizeof(float) * rows_pad * m0->C_pad));
     if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(p->d_acc2.ensure(sizeof(float) * rows_pad * m0->C_pad));
     AM_TRY(p->d_out.ensure(std::max<size_t>(sizeof(float) * N * m0->C, 16)));
     if (timedelay > 0 && N > 0) HIP_TRY(hipMemsetAsync(p->d_out.p, 0, sizeof(float) * N * m0->C, e->stream));  // yb = np.zeros(...)
     HIP_TRY(hipStreamSynchronize(e->stream));
+    p->drop_graph();
     p->n = N; p->n_packed = NP; p->n_slots = n_utts; p->has_ivec = ivec != nullptr;
     p->mode = 2;
     return AM_OK;
 }
+
+static int lstm_enqueue(am_pipeline* p);
 
 extern "C" int am_lstm_run(am_pipeline* p)
 {
@@ -717,6 +735,25 @@ extern "C" int am_lstm_run(am_pipeline* p)
     am_engine* e = p->e;
     HIP_TRY(hipSetDevice(e->device));
     if (p->n_packed == 0) return AM_OK;
+    if (e->profile) return lstm_enqueue(p);           // per-kernel events need eager launches
+    if (p->graph_exec) { HIP_TRY(hipGraphLaunch(p->graph_exec, e->stream)); return AM_OK; }
+    if (p->lstm_runs++ == 0) return lstm_enqueue(p);  // one-shot use: eager (no capture / instantiate cost)
+    // second run on the same upload: capture the launch sequence once, then replay it
+    HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = lstm_enqueue(p);
+    hipGraph_t g = nullptr;
+    hipError_t ce = hipStreamEndCapture(e->stream, &g);
+    if (rc != AM_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (ce != hipSuccess) return fail(AM_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+    p->graph = g;
+    HIP_TRY(hipGraphInstantiate(&p->graph_exec, p->graph, nullptr, nullptr, 0));
+    HIP_TRY(hipGraphLaunch(p->graph_exec, e->stream));
+    return AM_OK;
+}
+
+static int lstm_enqueue(am_pipeline* p)
+{
+    am_engine* e = p->e;
     am_model* m0 = p->members[0];
     const int64_t NP = p->n_packed, rows_pad = round_up(NP, GEMM_BM);
     const int64_t T = (int64_t)p->n_active.size();
@@ -728,27 +765,43 @@ extern "C" int am_lstm_run(am_pipeline* p)
     AM_TRY(run_kernel(e, K_GATHER_FT, [&] { return launch_gather_ft(e->stream, ga); }));
     for (int mi = 0; mi < (int)p->members.size(); ++mi) {
         am_model* m = p->members[mi];
-        const float* A = p->d_in.as<float>();
-        int lda = m->in_pad;
-        for (int l = 0; l < m->n_layers; ++l) {
-            Layer& Ly = m->L[l];
+        // layer 0: its input is known up front -> hoist the upward projection of ALL frames into one bulk GEMM
+        const int NL = m->n_layers;
+        const int U_pad = m->L[0].U_pad;
+        const size_t h_stride = (size_t)(rows_pad + GEMM_BM) * U_pad;   // per-layer H plane
+        const size_t c_stride = (size_t)round_up(std::max(p->n_slots, 1), 16) * U_pad;
+        {
+            Layer& L0 = m->L[0];
             GemmArgs g{};
-            g.A = A; g.lda = lda; g.W = Ly.W.as<float>(); g.ldw = Ly.in_pad; g.bias = Ly.b.as<float>();
-            g.C = p->d_G.as<float>(); g.ldc = Ly.out_pad; g.M_pad = (int)rows_pad; g.N_pad = Ly.out_pad; g.K_pad = Ly.in_pad;
+            g.A = p->d_in.as<float>(); g.lda = m->in_pad; g.W = L0.W.as<float>(); g.ldw = L0.in_pad; g.bias = L0.b.as<float>();
+            g.C = p->d_G.as<float>(); g.ldc = L0.out_pad; g.M_pad = (int)rows_pad; g.N_pad = L0.out_pad; g.K_pad = L0.in_pad;
             g.epi = EPI_LINEAR; g.alpha = 1.f;
             AM_TRY(run_kernel(e, K_LSTM_UPWARD, [&] { return launch_gemm(e->stream, g); }));
-            float* H = ((l & 1) ? p->d_H1 : p->d_H0).as<float>();
-            for (int64_t t = 0; t < T; ++t) {
-                LstmStepArgs s{};
-                s.G = p->d_G.as<float>() + p->step_off[t] * Ly.out_pad;
-                s.Hprev = t > 0 ? H + p->step_off[t - 1] * Ly.U_pad : H;
-                s.Wlat = Ly.Wlat.as<float>(); s.Cst = p->d_c.as<float>();
-                s.Hout = H + p->step_off[t] * Ly.U_pad;
-                s.n_active = p->n_active[t]; s.U_pad = Ly.U_pad; s.first = t == 0;
-                AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_step(e->stream, s); }));
-            }
-            A = H; lda = Ly.U_pad;
         }
+        // wavefront over (layer, time): launch d runs layer l at t = d - l; chain length T + NL - 1 instead of T * NL
+        float* Hall = p->d_H0.as<float>();
+        float* Call = p->d_c.as<float>();
+        for (int64_t d = 0; d < T + NL - 1; ++d) {
+            LstmWavefrontArgs w{};
+            w.U_pad = U_pad;
+            for (int l = 0; l < NL; ++l) {
+                const int64_t t = d - l;
+                if (t < 0 || t >= T) continue;
+                Layer& Ly = m->L[l];
+                LstmLayerStep& s = w.L[w.n++];
+                float* H = Hall + l * h_stride;
+                if (l == 0) { s.G = p->d_G.as<float>() + p->step_off[t] * Ly.out_pad; s.Hin = nullptr; }
+                else { s.G = nullptr; s.Hin = Hall + (l - 1) * h_stride + p->step_off[t] * U_pad; }
+                s.bias = Ly.b.as<float>(); s.Wup = Ly.W.as<float>(); s.Kin_pad = Ly.in_pad;
+                s.Hprev = t > 0 ? H + p->step_off[t - 1] * U_pad : H;
+                s.Wlat = Ly.Wlat.as<float>(); s.Cst = Call + l * c_stride;
+                s.Hout = H + p->step_off[t] * U_pad;
+                s.n_active = p->n_active[t]; s.first = t == 0;
+            }
+            AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_wavefront(e->stream, w); }));
+        }
+        const float* A = Hall + (size_t)(NL - 1) * h_stride;
+        const int lda = U_pad;
         Layer& Lo = m->L[m->n_layers];
         GemmArgs g{};
         g.A = A; g.lda = lda; g.W = Lo.W.as<float>(); g.ldw = Lo.in_pad; g.bias = Lo.b.as<float>();

@@ -72,14 +72,26 @@ struct GatherArgs {
 };
 hipError_t launch_gather_ft(hipStream_t s, const GatherArgs& a);
 
-struct LstmStepArgs {
-    const float* G;      // [>= rows, 4*U_pad] upward pre-activations of THIS step's rows, gate-tiled layout
-    const float* Hprev;  // [>= rows, U_pad]   previous step's outputs (same utterance order), unused if first
+constexpr int LSTM_MAX_LAYERS = 8;
+struct LstmLayerStep {   // one layer's time step inside a wavefront launch
+    const float* G;      // [>= rows, 4*U_pad] hoisted upward pre-activations (+bias) of this step's rows, or nullptr
+    const float* bias;   // [4*U_pad] gate-tiled, used when G == nullptr
+    const float* Hin;    // [>= rows, Kin_pad] this step's input rows (previous layer's h at the same t); nullptr with G
+    const float* Wup;    // [4*U_pad, Kin_pad] gate-tiled rows
+    const float* Hprev;  // [>= rows, U_pad]   previous step's h of this layer (same slot order), unused if first
     const float* Wlat;   // [4*U_pad, U_pad]   gate-tiled rows
-    float* Cst;          // [>= rows, U_pad]   cell state per utterance slot
+    float* Cst;          // [>= slots, U_pad]  cell state of this layer
     float* Hout;         // [>= rows, U_pad]
-    int n_active; int U_pad; int first;
+    int Kin_pad; int n_active; int first;
+    int block0;          // set by the launcher: first block of this layer in the launch
+    int tpb;             // set by the launcher: 16-row tiles per block (1..4)
 };
-hipError_t launch_lstm_step(hipStream_t s, const LstmStepArgs& a);
+struct LstmWavefrontArgs {
+    LstmLayerStep L[LSTM_MAX_LAYERS];
+    int n;               // layers active in this launch
+    int U_pad;           // common to all layers (multiple of 64)
+    int ut_groups;       // set by the launcher
+};
+hipError_t launch_lstm_wavefront(hipStream_t s, LstmWavefrontArgs& a);
 
 }  // namespace am

@@ -438,66 +438,176 @@ hipError_t launch_gather_ft(hipStream_t s, const GatherArgs& a)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Recurrent path, stage 2: one LSTM time step for the active utterances (first n_active slots).
-//   g = G[row] + Hprev[row] * Wlat^T ;  c' = tanh(a) sig(i) + sig(f) c ;  h' = sig(o) tanh(c')
+// Recurrent path, stage 2: one WAVEFRONT step of the LSTM stack.  Launch d computes, for every layer l, time step
+// t = d - l: the dependency chain of the whole stack is Tmax + L - 1 launches instead of Tmax * L (the path is
+// latency-bound: ~8 us per dependent launch).  Per layer and step, for the active utterances:
+//   g = [G[row] | bias + Hin[row] * Wup^T] + Hprev[row] * Wlat^T ;  c' = tanh(a) sig(i) + sig(f) c ;  h' = sig(o) tanh(c')
+// Layer 0 takes its upward term G from the hoisted bulk GEMM (its input is known up front); layers >= 1 fuse the upward
+// projection of the previous layer's h at the same t into the step (K = U + U).
 // Gate-tiled layout (host permutes weights): columns [64*j + 16*k + u'] hold gate k (a,i,f,o) of unit 16*j+u'.
-// Block = (16 utterances) x (16 units) x 4 gates; wave k computes gate k with v_mfma_f32_16x16x4_f32, operands
-// straight from global/L2 (each weight element is used by exactly one wave of the block, no LDS staging),
-// 4 consecutive k per 16-B load with the same K permutation trick as the GEMM.
+// 512 threads = 8 waves: wave = gate + 4*khalf (v_mfma_f32_16x16x4_f32; the K halves are combined through LDS).
+//   * loads the epilogue needs (G / bias, previous c) are issued first, then the A chunk, then the wave's weight
+//     fragments (each weight element is used by exactly one wave of the block: straight to VGPRs); vmcnt is in-order,
+//     so the A chunk is waited for while the weight loads are still in flight;
+//   * A goes through LDS (shared by the 8 waves; rows padded by 16 B -> conflict-free ds_read_b128) behind a raw
+//     s_barrier that does not drain the weight loads;
+//   * block -> (unit tile, row tile) keeps the row tiles of a unit tile on one XCD (blockIdx % 8) for L2 reuse.
+// K permutation as in the GEMM: 4 consecutive k per 16-B load feed 4 MFMAs, A and W alike.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lstm_step_kernel(
-    const float* __restrict__ G, const float* __restrict__ Hprev, const float* __restrict__ Wlat,
-    float* __restrict__ Cst, float* __restrict__ Hout, int n_active, int U_pad, int first)
+// Block = 64 utterance rows (4 MFMA row tiles) x 16 units x 4 gates; the wave's weight fragments stay in registers and
+// are reused by the 4 row tiles (4x less weight traffic per row than a 16-row block: the launch is L2-bandwidth-bound
+// otherwise).  K is walked in batches of LSTM_KB = 128 (64 per K half): the next batch's A chunk and weight fragments are
+// prefetched into registers while the current batch is multiplied.
+constexpr int LSTM_RB = 64;               // rows per block
+constexpr int LSTM_KB = 128;              // k per batch (both K halves)
+constexpr int LSTM_KS = LSTM_KB / 32;     // 16-k sub-steps per wave per batch
+constexpr int LSTM_LDA = LSTM_KB + 4;     // LDS row stride (floats): +16 B -> conflict-free ds_read_b128
+constexpr int LSTM_APT = LSTM_RB * LSTM_KB / 4 / 512;  // 16-B A chunks per thread per batch
+
+__global__ __launch_bounds__(512) void lstm_wavefront_kernel(const LstmWavefrontArgs args)
 {
-    __shared__ float sg[4][16][17];
-    const int ut = blockIdx.x, rt = blockIdx.y;
+    __shared__ __attribute__((aligned(16))) float sA[LSTM_RB * LSTM_LDA];
+    __shared__ float sg[2 * 4 * LSTM_RB * 17];
+    int li = 0;
+#pragma unroll
+    for (int l = 1; l < LSTM_MAX_LAYERS; ++l) if (l < args.n && (int)blockIdx.x >= args.L[l].block0) li = l;
+    const LstmLayerStep& Ls = args.L[li];
+    const int U_pad = args.U_pad, ut_groups = args.ut_groups;
+    const int bid = blockIdx.x - Ls.block0;
+    const int ut = (bid & 7) + 8 * ((bid >> 3) % ut_groups);
+    const int rt = (bid >> 3) / ut_groups;
+    if (ut * 16 >= U_pad) return;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int gate = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gate = wave & 3, kh = wave >> 2;
     const int l15 = lane & 15, lq = lane >> 4;
     const int ldg = 4 * U_pad;
+    const int first = Ls.first, n_active = Ls.n_active;
+    // this block's live 16-row tiles: [rt*tpb, rt*tpb + ntile) (tpb <= 4 is chosen by the launcher to fill the chip)
+    const int row0 = rt * Ls.tpb * 16;
+    const int tiles_left = (n_active - row0 + 15) / 16;
+    const int ntile = tiles_left < Ls.tpb ? tiles_left : Ls.tpb;
 
-    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (!first) {
-        const float* wrow = Wlat + (size_t)(ut * 64 + gate * 16 + l15) * U_pad + 4 * lq;
-        const float* arow = Hprev + (size_t)(rt * 16 + l15) * U_pad + 4 * lq;
-        const int steps = U_pad / 16;
-#pragma unroll 4
-        for (int s = 0; s < steps; ++s) {
-            const f32x4 a = *(const f32x4*)(arow + 16 * s);
-            const f32x4 w = *(const f32x4*)(wrow + 16 * s);
+    // loads the epilogue needs, issued first: they ride along with the operand loads instead of adding round trips
+    float gpre[2][4], cprev[2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w[j], acc, 0, 0, 0);
+    for (int e = 0; e < 2; ++e) {
+        const int idx = tid + 512 * e, erow = idx >> 4, eu = idx & 15, slot = row0 + erow;
+        const bool live = erow < ntile * 16 && slot < n_active;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            gpre[e][k] = !live ? 0.0f : (Ls.G ? Ls.G[(size_t)slot * ldg + ut * 64 + k * 16 + eu] : Ls.bias[ut * 64 + k * 16 + eu]);
+        cprev[e] = (!first && live) ? Ls.Cst[(size_t)slot * U_pad + ut * 16 + eu] : 0.0f;
+    }
+
+    // batches: segment 0 = upward projection of this step's input rows (layers >= 1), segment 1 = lateral term (t > 0)
+    const int nb0 = Ls.Hin ? Ls.Kin_pad / LSTM_KB : 0;
+    const int nb1 = first ? 0 : U_pad / LSTM_KB;
+    const int nb = nb0 + nb1;
+    auto batch_ptrs = [&](int b, const float*& ap, const float*& wp, int& K) {
+        if (b < nb0) { K = Ls.Kin_pad; ap = Ls.Hin + (size_t)row0 * K + b * LSTM_KB; wp = Ls.Wup + b * LSTM_KB; }
+        else { K = U_pad; ap = Ls.Hprev + (size_t)row0 * K + (b - nb0) * LSTM_KB; wp = Ls.Wlat + (b - nb0) * LSTM_KB; }
+        wp += (size_t)(ut * 64 + gate * 16 + l15) * K + kh * (LSTM_KB / 2) + 4 * lq;
+    };
+    f32x4 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 av[LSTM_APT], wv[LSTM_KS];
+    auto prefetch = [&](int b) {
+        const float* ap; const float* wp; int K;
+        batch_ptrs(b, ap, wp, K);
+#pragma unroll
+        for (int e = 0; e < LSTM_APT; ++e) {   // A chunk first: in-order vmcnt lets it be waited for before the weights
+            const int idx = tid + 512 * e, r = idx / (LSTM_KB / 4), c4 = idx % (LSTM_KB / 4);  // chunk e = row tile e
+            if (e < ntile) av[e] = *(const f32x4*)(ap + (size_t)r * K + 4 * c4);
+        }
+#pragma unroll
+        for (int s = 0; s < LSTM_KS; ++s) wv[s] = *(const f32x4*)(wp + 16 * s);
+    };
+    if (nb > 0) prefetch(0);
+    for (int b = 0; b < nb; ++b) {
+        if (b > 0) __syncthreads();           // everyone is done reading the previous batch's A tile
+#pragma unroll
+        for (int e = 0; e < LSTM_APT; ++e) {
+            const int idx = tid + 512 * e, r = idx / (LSTM_KB / 4), c4 = idx % (LSTM_KB / 4);
+            if (e < ntile) *(f32x4*)(sA + r * LSTM_LDA + 4 * c4) = av[e];
+        }
+        f32x4 wc[LSTM_KS];
+#pragma unroll
+        for (int s = 0; s < LSTM_KS; ++s) wc[s] = wv[s];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (b + 1 < nb) prefetch(b + 1);      // next batch flies while this one is multiplied
+#pragma unroll
+        for (int s = 0; s < LSTM_KS; ++s) {
+            f32x4 a[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < ntile) a[r] = *(const f32x4*)(sA + (r * 16 + l15) * LSTM_LDA + kh * (LSTM_KB / 2) + 16 * s + 4 * lq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)   // j outer, row tile inner: consecutive MFMAs hit different accumulators
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < ntile) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], wc[s][j], acc[r], 0, 0, 0);
         }
     }
     // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        const int row = lq * 4 + reg;
-        sg[gate][row][l15] = acc[reg] + G[(size_t)(rt * 16 + row) * ldg + ut * 64 + gate * 16 + l15];
-    }
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            sg[((kh * 4 + gate) * LSTM_RB + r * 16 + lq * 4 + reg) * 17 + l15] = acc[r][reg];
     __syncthreads();
-    const int row = tid >> 4, u = tid & 15;
-    const int slot = rt * 16 + row;
-    if (slot < n_active) {
-        const float a = tanhf(sg[0][row][u]);
-        const float i = am_sigmoid(sg[1][row][u]);
-        const float f = am_sigmoid(sg[2][row][u]);
-        const float o = am_sigmoid(sg[3][row][u]);
-        const size_t idx = (size_t)slot * U_pad + ut * 16 + u;
-        const float cprev = first ? 0.0f : Cst[idx];
-        const float ai = a * i;
-        const float fc = f * cprev;
-        const float c = ai + fc;
-        Cst[idx] = c;
-        Hout[idx] = o * tanhf(c);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int idx = tid + 512 * e, erow = idx >> 4, eu = idx & 15, slot = row0 + erow;
+        if (erow < ntile * 16 && slot < n_active) {
+            float pre[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                pre[k] = (sg[((0 * 4 + k) * LSTM_RB + erow) * 17 + eu] + sg[((1 * 4 + k) * LSTM_RB + erow) * 17 + eu]) + gpre[e][k];
+            const float a = tanhf(pre[0]);
+            const float i = am_sigmoid(pre[1]);
+            const float f = am_sigmoid(pre[2]);
+            const float o = am_sigmoid(pre[3]);
+            const float ai = a * i;
+            const float fc = f * cprev[e];
+            const float c = ai + fc;
+            const size_t cidx = (size_t)slot * U_pad + ut * 16 + eu;
+            Ls.Cst[cidx] = c;
+            Ls.Hout[cidx] = o * tanhf(c);
+        }
     }
 }
 
-hipError_t launch_lstm_step(hipStream_t s, const LstmStepArgs& a)
+static int lstm_blocks_for(int n_active, int U_pad, int tpb)
 {
-    if (a.n_active <= 0) return hipSuccess;
-    dim3 grid(a.U_pad / 16, (a.n_active + 15) / 16);
-    hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(256), 0, s, a.G, a.Hprev, a.Wlat, a.Cst, a.Hout, a.n_active, a.U_pad, a.first);
+    const int n_ut = U_pad / 16, ut_groups = (n_ut + 7) / 8, n_tiles = (n_active + 15) / 16;
+    return 8 * ut_groups * ((n_tiles + tpb - 1) / tpb);
+}
+
+hipError_t launch_lstm_wavefront(hipStream_t s, LstmWavefrontArgs& a)
+{
+    if (a.n <= 0 || a.n > LSTM_MAX_LAYERS || a.U_pad % LSTM_KB) return hipErrorInvalidValue;
+    a.ut_groups = (a.U_pad / 16 + 7) / 8;
+    // row tiles per block: the largest of {4, 2, 1} that still yields >= 256 blocks (one per CU); more rows per block
+    // reuse each weight fragment more, fewer rows per block keep every CU busy when few utterances are still active
+    int tpb = 4;
+    for (; tpb > 1; tpb >>= 1) {
+        int blocks = 0;
+        for (int l = 0; l < a.n; ++l) blocks += lstm_blocks_for(a.L[l].n_active, a.U_pad, tpb);
+        if (blocks >= 256) break;
+    }
+    int total = 0;
+    for (int l = 0; l < a.n; ++l) {
+        const int n_tiles = (a.L[l].n_active + 15) / 16, n_rt = (n_tiles + tpb - 1) / tpb;
+        a.L[l].tpb = n_rt > 0 ? (n_tiles + n_rt - 1) / n_rt : 1;   // balanced: ceil(tiles / row blocks)
+        a.L[l].block0 = total;
+        total += 8 * a.ut_groups * n_rt;
+        if (a.L[l].Hin && a.L[l].Kin_pad % LSTM_KB) return hipErrorInvalidValue;
+    }
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(lstm_wavefront_kernel, dim3(total), dim3(512), 0, s, a);
     return hipGetLastError();
 }
 

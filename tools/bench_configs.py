@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Secondary measurements for DESIGN.md: the other BASELINE.json configs on one MI355X (device-resident, like bench.py).
+
+  configs[1'] 4x1024 on N=57,919 (core-test-like, 192 utterances)     configs[2] 6x2048 + 100 i-vector columns
+  configs[3]  3x512 LSTM (uni-directional), timedelay 0/5  configs[4] 10-member ensemble / dev-average
+Prints one JSON object per line.  Not the headline benchmark (that is bench.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nnacousticmodeling_amd._lib import AM_COMBINE_LOGITS, AM_COMBINE_LOGPOST  # noqa: E402
+from nnacousticmodeling_amd.engine import Engine, Model, Pipeline  # noqa: E402
+from oracle import am_oracle as orc  # noqa: E402  (synthetic-input helpers only)
+
+SEED = 20181806
+
+
+def timed(eng, fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    eng.synchronize()
+    timed.unprofiled_ms = (time.perf_counter() - t0) / steps * 1e3
+    eng.profile(True)
+    eng.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    eng.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    prof = eng.profile_read()
+    eng.profile(False)
+    return wall, {k: round(v[1] / steps, 4) for k, v in prof.items()}, {k: v[0] // steps for k, v in prof.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--which", default="all")
+    ap.add_argument("--steps", type=int, default=5)
+    args = ap.parse_args()
+    rng = np.random.default_rng(SEED)
+    golden = os.path.join(ROOT, "tests", "golden")
+    ft = orc.load_kaldi_feature_transform(os.path.join(golden, "final.feature_transform"))
+    ftc = orc.centre_frame_transform(ft)
+    eng = Engine(0)
+    N = 57919
+    offsets = orc.make_offsets(rng, 192, N)
+    x = rng.standard_normal((N, 40)).astype(np.float32)
+
+    def report(name, frames, wall, ms, calls, flops_per_frame):
+        un = timed.unprofiled_ms
+        print(json.dumps({"config": name, "frames": frames, "ms_per_pass_unprofiled": round(un, 3), "frames_per_s_unprofiled": round(frames / un * 1e3),
+                          "ms_per_pass": round(wall * 1e3, 3), "frames_per_s": round(frames / wall),
+                          "tflops": round(frames * flops_per_frame / wall / 1e12, 2), "kernels_ms": ms, "launches": calls}), flush=True)
+
+    if args.which in ("all", "ff"):
+        for name, layers, units, d_iv, n in (("4x1024 N=57919", 4, 1024, 0, N), ("6x2048+ivec N=57919", 6, 2048, 100, N), ("6x2048+ivec N=196608", 6, 2048, 100, 196608)):
+            params = orc.make_mlp_params(rng, 440 + d_iv, units, layers, 1909)
+            xx = x if n == N else rng.standard_normal((n, 40)).astype(np.float32)
+            iv = rng.standard_normal((n, d_iv)).astype(np.float32) if d_iv else None
+            p = Pipeline(eng)
+            p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"], d_iv)
+            p.set_members([Model(eng, "ff", layers, params)])
+            p.ff_upload(xx, iv, n, 0, 0)
+            wall, ms, calls = timed(eng, p.ff_run, args.steps, 2)
+            fl = 2 * ((440 + d_iv) * units + (layers - 1) * units * units + units * 1909)
+            report(name, n, wall, ms, calls, fl)
+            p.close()
+    if args.which in ("all", "lstm"):
+        params = orc.make_lstm_params(rng, 40, 512, 3, 1909)
+        m = Model(eng, "lstm", 3, params)
+        for td in (0, 5):
+            p = Pipeline(eng)
+            p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
+            p.set_members([m])
+            p.lstm_upload(x, None, offsets, td)
+            wall, ms, calls = timed(eng, p.lstm_run, args.steps, 1)
+            fl = 2 * (40 * 2048 + 2 * 512 * 2048 + 3 * 512 * 2048 + 512 * 1909)
+            report("3x512 LSTM N=57919 192 utts Tmax=%d timedelay=%d" % (int(np.diff(offsets).max()), td), N, wall, ms, calls, fl)
+            p.close()
+    if args.which in ("all", "ens"):
+        plist = [orc.make_mlp_params(rng, 440, 1024, 4, 1909) for _ in range(10)]
+        models = [Model(eng, "ff", 4, q) for q in plist]
+        for name, comb, master in (("10-fold dev-average (log-posterior mean)", AM_COMBINE_LOGPOST, False), ("master + 9 folds logit average", AM_COMBINE_LOGITS, True)):
+            p = Pipeline(eng)
+            p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+            p.set_members(models, has_master=master, combine=comb)
+            p.ff_upload(x, None, N, 0, 0)
+            wall, ms, calls = timed(eng, p.ff_run, max(2, args.steps // 2), 1)
+            report(name + " N=57919", N, wall, ms, calls, 10 * 11102208)
+            p.close()
+
+
+if __name__ == "__main__":
+    main()
