@@ -56,6 +56,25 @@ def make_workload(model, frames, rank):
     return ft, params, layers, x, iv, d_iv
 
 
+def pmc_traffic(kernel_prefix="am::gemm_nt_f32_kernel"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (tools_prof.sh -> tools/summarise_profiles.py): (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 correction of
+    MI355X_MICROARCH.md (FETCH_SIZE counts half of a 16-B-per-lane streaming read), averaged over the kernel's launches.
+    PMC counters cannot be collected from inside the process, so this is read from profiles/ (None if absent)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None, None
+    summ = json.load(open(files[-1]))
+    tot, n = 0.0, 0
+    for k, v in summ.items():
+        if kernel_prefix in k and "derived_hbm_bytes_per_launch" in v:
+            ln = v["FETCH_SIZE"]["launches"]
+            tot += v["derived_hbm_bytes_per_launch"] * ln
+            n += ln
+    return (tot / n if n else None), os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(ft, params, layers, x, iv, seconds):
     """The oracle (numpy restatement of the Chainer CPU forward, kind = "port") on a bounded sample of the same file:
     predict()'s own batching -- 1024-frame batches: prepareBatch -> transform -> MLP -> y - logsum(y)."""
@@ -127,6 +146,7 @@ def main():
         gemm_ms = sum(prof[k][1] for k in ("gemm_hidden", "gemm_out") if k in prof)
         flops_step = FLOPS_PER_FRAME[args.model] * args.frames
         achieved = flops_step * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
+        traffic, traffic_src = pmc_traffic() if (args.model == "4x1024" and args.frames == 196608) else (None, None)
         out = {
             "metric": "frames/sec (posterior compute), %s ReLU DNN, fbank40 splice+-5, fp32" % args.model,
             "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -138,7 +158,9 @@ def main():
             "device_ms_per_step": dev_ms / args.steps,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_f32_kernel (all Linear layers: %d launches/step)" % (gemm_calls // max(args.steps, 1)),
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": None,
+                         "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC, %s)" % traffic_src if traffic else None,
+                         "algorithmic_bytes_per_launch": (args.frames * 4 * (440 + 4 * 1024 + 4 * 1024 + 1909) + 4 * (440 * 1024 + 3 * 1024 * 1024 + 1024 * 1909)) / 5.0 if args.model == "4x1024" else None,
                          "avg_launch_ms": gemm_ms / gemm_calls if gemm_calls else None},
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
         }

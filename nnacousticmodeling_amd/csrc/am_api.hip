@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -65,7 +66,10 @@ struct DevBuf {
 
 struct am_engine {
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // compute stream: every GEMM / frontend / recurrent kernel
+    hipStream_t stream2 = nullptr;   // epilogue stream: the HBM-bound finish pass of chunk c overlaps the MFMA-bound GEMMs of chunk c+1
+    hipEvent_t s2_tail = nullptr;    // last work enqueued on stream2
+    bool s2_dirty = false;
     hipEvent_t ev[64] = {};
     bool profile = false;
     struct Rec { int id; hipEvent_t a, b; };
@@ -109,7 +113,10 @@ struct am_pipeline {
     int64_t n = 0;
     int halo_lo = 0, halo_hi = 0;
     bool has_ivec = false;
-    DevBuf d_x, d_ivec, d_in, d_act0, d_act1, d_acc, d_acc2, d_out;
+    DevBuf d_x, d_ivec, d_in, d_act0, d_act1, d_acc, d_accB, d_acc2, d_out;
+    hipEvent_t acc_ready[2] = {}, fin_done[2] = {};  // logits buffer hand-off between the compute and epilogue streams
+    bool fin_pending[2] = {false, false};
+    uint64_t chunk_seq = 0;
     // lstm
     DevBuf d_src, d_dst, d_G, d_H0, d_H1, d_c;
     std::vector<int64_t> step_off;
@@ -128,35 +135,59 @@ struct am_pipeline {
     }
 };
 
-static constexpr int64_t FF_CHUNK_ROWS = 1 << 18;
+// Rows per feed-forward chunk (bounds the activation workspace) and whether the finish pass runs on the epilogue stream.
+// Tunables for experiments: AM_FF_CHUNK_ROWS (multiple of 256), AM_FF_OVERLAP (0/1).
+static int64_t env_int(const char* name, int64_t dflt)
+{
+    const char* v = getenv(name);
+    return v && *v ? atoll(v) : dflt;
+}
+static const int64_t FF_CHUNK_ROWS = std::max<int64_t>(GEMM_BM, env_int("AM_FF_CHUNK_ROWS", 1 << 18) / GEMM_BM * GEMM_BM);
+static const bool FF_OVERLAP = env_int("AM_FF_OVERLAP", 0) != 0;
 
 // ----------------------------------------------------------------------------------------------------
 // kernel launch with optional event bracketing
 // ----------------------------------------------------------------------------------------------------
 template <class F>
-static int run_kernel(am_engine* e, int id, F&& launch)
+static int run_kernel(am_engine* e, int id, F&& launch, hipStream_t on = nullptr)
 {
+    hipStream_t st = on ? on : e->stream;
     hipEvent_t a = nullptr, b = nullptr;
     if (e->profile) {
         for (hipEvent_t* ev : {&a, &b}) {
             if (!e->pool.empty()) { *ev = e->pool.back(); e->pool.pop_back(); }
             else HIP_TRY(hipEventCreate(ev));
         }
-        HIP_TRY(hipEventRecord(a, e->stream));
+        HIP_TRY(hipEventRecord(a, st));
     }
     hipError_t r = launch();
     if (r != hipSuccess) return fail(AM_EHIP, "launch of %s failed: %s", am_kernel_name(id), hipGetErrorString(r));
     if (e->profile) {
-        HIP_TRY(hipEventRecord(b, e->stream));
+        HIP_TRY(hipEventRecord(b, st));
         e->recs.push_back({id, a, b});
     }
+    return AM_OK;
+}
+
+// make the compute stream wait (on the device) for everything enqueued on the epilogue stream
+static int join_streams(am_engine* e)
+{
+    if (e->s2_dirty) { HIP_TRY(hipStreamWaitEvent(e->stream, e->s2_tail, 0)); e->s2_dirty = false; }
+    return AM_OK;
+}
+
+static int sync_all(am_engine* e)
+{
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream2));
+    e->s2_dirty = false;
     return AM_OK;
 }
 
 static int drain_profile(am_engine* e)
 {
     if (e->recs.empty()) return AM_OK;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    AM_TRY(sync_all(e));
     for (auto& r : e->recs) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
@@ -203,7 +234,9 @@ extern "C" int am_engine_create(int device, am_engine** out)
     am_engine* e = new am_engine();
     e->device = device;
     snprintf(e->name, sizeof(e->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
-    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(AM_EHIP, "hipStreamCreate failed"); }
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->s2_tail, hipEventDisableTiming) != hipSuccess) { delete e; return fail(AM_EHIP, "hipStreamCreate failed"); }
     hipError_t r = init_kernels();
     if (r != hipSuccess) { (void)hipStreamDestroy(e->stream); delete e; return fail(AM_EHIP, "kernel init failed: %s", hipGetErrorString(r)); }
     *out = e;
@@ -215,6 +248,9 @@ extern "C" int am_engine_destroy(am_engine* e)
     if (!e) return AM_OK;
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
+    (void)hipStreamSynchronize(e->stream2);
+    (void)hipEventDestroy(e->s2_tail);
+    (void)hipStreamDestroy(e->stream2);
     for (auto& r : e->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -228,8 +264,7 @@ extern "C" int am_engine_synchronize(am_engine* e)
 {
     if (!e) return fail(AM_EINVAL, "engine is NULL");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    return AM_OK;
+    return sync_all(e);
 }
 
 extern "C" int am_engine_device_name(am_engine* e, char* buf, int buflen)
@@ -244,6 +279,7 @@ extern "C" int am_event_record(am_engine* e, int slot)
     if (!e || slot < 0 || slot >= 64) return fail(AM_EINVAL, "bad event slot");
     HIP_TRY(hipSetDevice(e->device));
     if (!e->ev[slot]) HIP_TRY(hipEventCreate(&e->ev[slot]));
+    AM_TRY(join_streams(e));  // the event covers the epilogue stream's pending work too
     HIP_TRY(hipEventRecord(e->ev[slot], e->stream));
     return AM_OK;
 }
@@ -295,7 +331,7 @@ static int upload(am_engine* e, DevBuf& d, const std::vector<float>& h)
 {
     AM_TRY(d.ensure(h.size() * sizeof(float)));
     HIP_TRY(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    AM_TRY(sync_all(e));
     return AM_OK;
 }
 
@@ -396,9 +432,11 @@ extern "C" int am_pipeline_destroy(am_pipeline* p)
     if (!p) return AM_OK;
     (void)hipSetDevice(p->e->device);
     (void)hipStreamSynchronize(p->e->stream);
+    (void)hipStreamSynchronize(p->e->stream2);
+    for (int i = 0; i < 2; ++i) { if (p->acc_ready[i]) (void)hipEventDestroy(p->acc_ready[i]); if (p->fin_done[i]) (void)hipEventDestroy(p->fin_done[i]); }
     p->drop_graph();
     for (DevBuf* d : {&p->d_shifts, &p->d_add, &p->d_scale, &p->d_rplw, &p->d_rplb, &p->d_rpllb, &p->d_prior, &p->d_x, &p->d_ivec, &p->d_in,
-                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_src, &p->d_dst, &p->d_G, &p->d_H0, &p->d_H1, &p->d_c})
+                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_accB, &p->d_acc2, &p->d_out, &p->d_src, &p->d_dst, &p->d_G, &p->d_H0, &p->d_H1, &p->d_c})
         d->release();
     delete p;
     return AM_OK;
@@ -409,7 +447,7 @@ extern "C" int am_pipeline_set_frontend(am_pipeline* p, int D, int n_shifts, con
     if (!p || D <= 0 || n_shifts <= 0 || !shifts || d_iv < 0) return fail(AM_EINVAL, "am_pipeline_set_frontend: bad argument");
     if ((add_shift == nullptr) != (rescale == nullptr)) return fail(AM_EINVAL, "am_pipeline_set_frontend: add_shift and rescale must both be given or both NULL");
     HIP_TRY(hipSetDevice(p->e->device));
-    HIP_TRY(hipStreamSynchronize(p->e->stream));
+    AM_TRY(sync_all(p->e));
     p->D = D; p->n_shifts = n_shifts; p->d_iv = d_iv; p->has_ft = add_shift != nullptr;
     AM_TRY(p->d_shifts.ensure(sizeof(int) * n_shifts));
     HIP_TRY(hipMemcpyAsync(p->d_shifts.p, shifts, sizeof(int) * n_shifts, hipMemcpyHostToDevice, p->e->stream));
@@ -420,7 +458,7 @@ extern "C" int am_pipeline_set_frontend(am_pipeline* p, int D, int n_shifts, con
         HIP_TRY(hipMemcpyAsync(p->d_add.p, add_shift, bytes, hipMemcpyHostToDevice, p->e->stream));
         HIP_TRY(hipMemcpyAsync(p->d_scale.p, rescale, bytes, hipMemcpyHostToDevice, p->e->stream));
     }
-    HIP_TRY(hipStreamSynchronize(p->e->stream));
+    AM_TRY(sync_all(p->e));
     p->mode = 0; p->drop_graph();
     return AM_OK;
 }
@@ -447,7 +485,7 @@ static int set_vec(am_pipeline* p, DevBuf& d, const float* src, int c)
 {
     AM_TRY(d.ensure(sizeof(float) * c));
     HIP_TRY(hipMemcpyAsync(d.p, src, sizeof(float) * c, hipMemcpyHostToDevice, p->e->stream));
-    HIP_TRY(hipStreamSynchronize(p->e->stream));
+    AM_TRY(sync_all(p->e));
     return AM_OK;
 }
 
@@ -458,7 +496,7 @@ extern "C" int am_pipeline_set_rpl4(am_pipeline* p, const float* W, const float*
     if (!W || !b || !lb) return fail(AM_EINVAL, "am_pipeline_set_rpl4: W, b, lb must all be given");
     if (p->members.empty()) return fail(AM_EINVAL, "am_pipeline_set_rpl4: set the members first");
     HIP_TRY(hipSetDevice(p->e->device));
-    HIP_TRY(hipStreamSynchronize(p->e->stream));
+    AM_TRY(sync_all(p->e));
     const int c = p->members[0]->C;
     AM_TRY(set_vec(p, p->d_rplw, W, c));
     AM_TRY(set_vec(p, p->d_rplb, b, c));
@@ -473,7 +511,7 @@ extern "C" int am_pipeline_set_prior(am_pipeline* p, const float* ap)
     if (!ap) { p->has_prior = false; p->drop_graph(); return AM_OK; }
     if (p->members.empty()) return fail(AM_EINVAL, "am_pipeline_set_prior: set the members first");
     HIP_TRY(hipSetDevice(p->e->device));
-    HIP_TRY(hipStreamSynchronize(p->e->stream));
+    AM_TRY(sync_all(p->e));
     AM_TRY(set_vec(p, p->d_prior, ap, p->members[0]->C));
     p->has_prior = true; p->drop_graph();
     return AM_OK;
@@ -528,18 +566,19 @@ static int member_finish(am_pipeline* p, int mi, int64_t rows)
     return run_kernel(p->e, K_FINISH, [&] { return launch_finish(p->e->stream, f); });
 }
 
-static int final_finish(am_pipeline* p, int64_t rows, float* out, const int* row_map)
+static int final_finish(am_pipeline* p, int64_t rows, float* out, const int* row_map, const float* in = nullptr, hipStream_t on = nullptr)
 {
     am_model* m0 = p->members[0];
     FinishArgs f{};
-    f.in = (p->combine == AM_COMBINE_LOGPOST ? p->d_acc2 : p->d_acc).as<float>(); f.ldin = m0->C_pad;
+    f.in = in ? in : (p->combine == AM_COMBINE_LOGPOST ? p->d_acc2 : p->d_acc).as<float>(); f.ldin = m0->C_pad;
     f.out = out; f.ldout = m0->C; f.row_map = row_map;
     f.n = rows; f.C = m0->C;
     f.divisor = final_divisor(p);
     if (p->has_rpl) { f.rpl_w = p->d_rplw.as<float>(); f.rpl_b = p->d_rplb.as<float>(); f.rpl_lb = p->d_rpllb.as<float>(); }
     if (p->has_prior) f.prior = p->d_prior.as<float>();
     f.normalise = p->normalise;
-    return run_kernel(p->e, K_FINISH, [&] { return launch_finish(p->e->stream, f); });
+    hipStream_t st = on ? on : p->e->stream;
+    return run_kernel(p->e, K_FINISH, [&] { return launch_finish(st, f); }, st);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -548,11 +587,11 @@ static int final_finish(am_pipeline* p, int64_t rows, float* out, const int* row
 extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, int64_t n, int halo_lo, int halo_hi)
 {
     AM_TRY(check_ready(p, AM_NET_FF));
-    if (!x || n < 0 || halo_lo < 0 || halo_hi < 0) return fail(AM_EINVAL, "am_ff_upload: bad argument");
+    if ((!x && halo_lo + n + halo_hi > 0) || n < 0 || halo_lo < 0 || halo_hi < 0) return fail(AM_EINVAL, "am_ff_upload: bad argument");
     if ((p->d_iv > 0) != (ivec != nullptr)) return fail(AM_EINVAL, "am_ff_upload: i-vectors %s", p->d_iv > 0 ? "expected but NULL" : "given but the frontend has d_iv = 0");
     am_engine* e = p->e;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    AM_TRY(sync_all(e));
     am_model* m0 = p->members[0];
     const int64_t ext = halo_lo + n + halo_hi;
     if (n > 0 && ext <= 0) return fail(AM_EINVAL, "am_ff_upload: empty input");
@@ -571,15 +610,16 @@ extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, i
         AM_TRY(p->d_act1.ensure(sizeof(float) * rows * width));
     }
     AM_TRY(p->d_acc.ensure(sizeof(float) * rows * m0->C_pad));
+    AM_TRY(p->d_accB.ensure(sizeof(float) * rows * m0->C_pad));
     if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(p->d_acc2.ensure(sizeof(float) * rows * m0->C_pad));
     AM_TRY(p->d_out.ensure(std::max<size_t>(sizeof(float) * n * m0->C, 16)));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    AM_TRY(sync_all(e));
     p->n = n; p->halo_lo = halo_lo; p->halo_hi = halo_hi; p->has_ivec = ivec != nullptr;
     p->mode = 1;
     return AM_OK;
 }
 
-static int ff_member_forward(am_pipeline* p, int mi, int64_t rows_pad)
+static int ff_member_forward(am_pipeline* p, int mi, int64_t rows_pad, float* acc)
 {
     am_engine* e = p->e;
     am_model* m = p->members[mi];
@@ -595,7 +635,7 @@ static int ff_member_forward(am_pipeline* p, int mi, int64_t rows_pad)
             g.C = ((l & 1) ? p->d_act1 : p->d_act0).as<float>(); g.ldc = Ly.out_pad; g.epi = EPI_ACT; g.alpha = 1.f;
             id = K_GEMM_HIDDEN;
         } else {
-            g.C = p->d_acc.as<float>(); g.ldc = m->C_pad; g.epi = epilogue_mode(p, mi, &g.alpha);
+            g.C = acc; g.ldc = m->C_pad; g.epi = epilogue_mode(p, mi, &g.alpha);
             id = K_GEMM_OUT;
         }
         AM_TRY(run_kernel(e, id, [&] { return launch_gemm(e->stream, g); }));
@@ -620,11 +660,30 @@ extern "C" int am_ff_run(am_pipeline* p)
         s.add = p->has_ft ? p->d_add.as<float>() : nullptr; s.scale = p->has_ft ? p->d_scale.as<float>() : nullptr;
         s.d_iv = p->d_iv; s.out = p->d_in.as<float>(); s.ldo = m0->in_pad;
         AM_TRY(run_kernel(e, K_SPLICE_FT, [&] { return launch_splice_ft(e->stream, s); }));
+        // The finish pass (HBM-bound) of this chunk runs on the epilogue stream and overlaps the MFMA-bound GEMMs of the
+        // next chunk / next run; the logits buffer is double-buffered and handed over with events.
+        const bool overlap = FF_OVERLAP && p->combine == AM_COMBINE_LOGITS;
+        const int par = overlap ? (int)(p->chunk_seq++ & 1) : 0;
+        float* acc = (par ? p->d_accB : p->d_acc).as<float>();
+        if (overlap && p->fin_pending[par]) {   // the finish pass that last read this buffer must be done before it is overwritten
+            HIP_TRY(hipStreamWaitEvent(e->stream, p->fin_done[par], 0));
+            p->fin_pending[par] = false;
+        }
         for (int mi = 0; mi < (int)p->members.size(); ++mi) {
-            AM_TRY(ff_member_forward(p, mi, nc_pad));
+            AM_TRY(ff_member_forward(p, mi, nc_pad, acc));
             if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(member_finish(p, mi, nc));
         }
-        AM_TRY(final_finish(p, nc, p->d_out.as<float>() + c0 * m0->C, nullptr));
+        float* out = p->d_out.as<float>() + c0 * m0->C;
+        if (!overlap) { AM_TRY(final_finish(p, nc, out, nullptr)); continue; }
+        for (hipEvent_t* ev : {&p->acc_ready[par], &p->fin_done[par]})
+            if (!*ev) HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(p->acc_ready[par], e->stream));
+        HIP_TRY(hipStreamWaitEvent(e->stream2, p->acc_ready[par], 0));
+        AM_TRY(final_finish(p, nc, out, nullptr, acc, e->stream2));
+        HIP_TRY(hipEventRecord(p->fin_done[par], e->stream2));
+        HIP_TRY(hipEventRecord(e->s2_tail, e->stream2));
+        p->fin_pending[par] = true;
+        e->s2_dirty = true;
     }
     return AM_OK;
 }
@@ -634,8 +693,9 @@ extern "C" int am_ff_download(am_pipeline* p, float* y)
     if (!p || p->mode != 1 || !y) return fail(AM_EINVAL, "am_ff_download: nothing to download");
     am_engine* e = p->e;
     HIP_TRY(hipSetDevice(e->device));
+    AM_TRY(join_streams(e));
     if (p->n > 0) HIP_TRY(hipMemcpyAsync(y, p->d_out.p, sizeof(float) * p->n * p->members[0]->C, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    AM_TRY(sync_all(e));
     return AM_OK;
 }
 
@@ -652,13 +712,13 @@ extern "C" int am_forward_ff(am_pipeline* p, const float* x, const float* ivec, 
 extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec, const int64_t* offsets, int n_utts, int timedelay)
 {
     AM_TRY(check_ready(p, AM_NET_LSTM));
-    if (!x || !offsets || n_utts < 0 || timedelay < 0) return fail(AM_EINVAL, "am_lstm_upload: bad argument");
+    if (!offsets || n_utts < 0 || timedelay < 0 || (!x && offsets[n_utts] > 0)) return fail(AM_EINVAL, "am_lstm_upload: bad argument");
     if (p->n_shifts != 1) return fail(AM_EINVAL, "am_lstm_upload: the recurrent path takes un-spliced frames (n_shifts must be 1)");
     if ((p->d_iv > 0) != (ivec != nullptr)) return fail(AM_EINVAL, "am_lstm_upload: i-vector argument does not match the frontend");
     if (offsets[0] != 0) return fail(AM_EINVAL, "am_lstm_upload: offsets[0] must be 0");
     am_engine* e = p->e;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    AM_TRY(sync_all(e));
     am_model* m0 = p->members[0];
     const int64_t N = offsets[n_utts];
     std::vector<int64_t> len(n_utts);
@@ -720,7 +780,7 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
     if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(p->d_acc2.ensure(sizeof(float) * rows_pad * m0->C_pad));
     AM_TRY(p->d_out.ensure(std::max<size_t>(sizeof(float) * N * m0->C, 16)));
     if (timedelay > 0 && N > 0) HIP_TRY(hipMemsetAsync(p->d_out.p, 0, sizeof(float) * N * m0->C, e->stream));  // yb = np.zeros(...)
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    AM_TRY(sync_all(e));
     p->drop_graph();
     p->n = N; p->n_packed = NP; p->n_slots = n_utts; p->has_ivec = ivec != nullptr;
     p->mode = 2;
@@ -818,8 +878,9 @@ extern "C" int am_lstm_download(am_pipeline* p, float* y)
     if (!p || p->mode != 2 || !y) return fail(AM_EINVAL, "am_lstm_download: nothing to download");
     am_engine* e = p->e;
     HIP_TRY(hipSetDevice(e->device));
+    AM_TRY(join_streams(e));
     if (p->n > 0) HIP_TRY(hipMemcpyAsync(y, p->d_out.p, sizeof(float) * p->n * p->members[0]->C, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    AM_TRY(sync_all(e));
     return AM_OK;
 }
 
@@ -848,7 +909,7 @@ extern "C" int am_frontend_apply(am_pipeline* p, const float* x, const float* iv
     if (n == 0) return AM_OK;
     am_engine* e = p->e;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    AM_TRY(sync_all(e));
     const int width = p->n_shifts * p->D + p->d_iv;
     const int ldo = (int)round_up(width, GEMM_BK);
     const int64_t ext = halo_lo + n + halo_hi;
@@ -867,7 +928,7 @@ extern "C" int am_frontend_apply(am_pipeline* p, const float* x, const float* iv
     s.d_iv = p->d_iv; s.out = e->scratch[2].as<float>(); s.ldo = ldo;
     AM_TRY(run_kernel(e, K_SPLICE_FT, [&] { return launch_splice_ft(e->stream, s); }));
     HIP_TRY(hipMemcpy2DAsync(out, sizeof(float) * width, e->scratch[2].p, sizeof(float) * ldo, sizeof(float) * width, n, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    AM_TRY(sync_all(e));
     return AM_OK;
 }
 
@@ -876,7 +937,7 @@ extern "C" int am_lognormalise(am_engine* e, float* lp, int64_t n, int c, const 
     if (!e || !lp || n < 0 || c <= 0 || c > 2048) return fail(AM_EINVAL, "am_lognormalise: bad argument");
     if (n == 0) return AM_OK;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    AM_TRY(sync_all(e));
     AM_TRY(e->scratch[0].ensure(sizeof(float) * n * c));
     HIP_TRY(hipMemcpyAsync(e->scratch[0].p, lp, sizeof(float) * n * c, hipMemcpyHostToDevice, e->stream));
     if (ap) {
@@ -888,7 +949,7 @@ extern "C" int am_lognormalise(am_engine* e, float* lp, int64_t n, int c, const 
     f.n = n; f.C = c; f.prior = ap ? e->scratch[1].as<float>() : nullptr; f.normalise = 1;
     AM_TRY(run_kernel(e, K_FINISH, [&] { return launch_finish(e->stream, f); }));
     HIP_TRY(hipMemcpyAsync(lp, e->scratch[0].p, sizeof(float) * n * c, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    AM_TRY(sync_all(e));
     return AM_OK;
 }
 
@@ -897,7 +958,7 @@ extern "C" int am_linear(am_engine* e, const float* x, int64_t n, int in_dim, co
     if (!e || !x || !W || !y || n < 0 || in_dim <= 0 || out_dim <= 0 || act > AM_ACT_TANH) return fail(AM_EINVAL, "am_linear: bad argument");
     if (n == 0) return AM_OK;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    AM_TRY(sync_all(e));
     const int kp = (int)round_up(in_dim, GEMM_BK), np = gemm_n_pad(out_dim);
     const int64_t mp = round_up(n, GEMM_BM);
     AM_TRY(e->scratch[0].ensure(sizeof(float) * mp * kp));
@@ -916,6 +977,6 @@ extern "C" int am_linear(am_engine* e, const float* x, int64_t n, int in_dim, co
     g.act = act < 0 ? 0 : act; g.epi = act < 0 ? EPI_LINEAR : EPI_ACT; g.alpha = 1.f;
     AM_TRY(run_kernel(e, K_GEMM_HIDDEN, [&] { return launch_gemm(e->stream, g); }));
     HIP_TRY(hipMemcpy2DAsync(y, sizeof(float) * out_dim, e->scratch[3].p, sizeof(float) * np, sizeof(float) * out_dim, n, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    AM_TRY(sync_all(e));
     return AM_OK;
 }
