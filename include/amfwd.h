@@ -17,6 +17,7 @@
 #ifndef AMFWD_H
 #define AMFWD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -70,6 +71,11 @@ int am_profile_reset(am_engine* e);
 int am_profile_read(am_engine* e, int64_t calls[AM_KERNEL_ID_MAX], double ms[AM_KERNEL_ID_MAX]);
 const char* am_kernel_name(int kernel_id); /* NULL when out of range */
 
+/* Page-locked host memory visible to every GPU (hipHostMallocPortable): posteriors land in it at PCIe line rate and
+ * am_forward_ff overlaps the copies with compute.  Optional: every entry point also accepts ordinary (pageable) arrays. */
+int am_host_alloc(size_t bytes, void** out);
+int am_host_free(void* ptr);
+
 /* ---- models --------------------------------------------------------------------------------------- */
 /* replaces get_nn + L.Classifier + serializers.load_npz (chainer_networks.py:163-184, evaluate.py:134-136,
  * predict_folds.py:153-157,206).  Weights in Chainer layout:
@@ -119,7 +125,8 @@ int am_pipeline_set_normalise(am_pipeline* p, int on);
  * unless the shard touches the start/end of the file (global clamp, kw_utils.py:29-33).
  * ivec: [n, d_iv] or NULL.  am_ff_upload copies to HBM; am_ff_run launches the whole device path on the
  * compute stream (asynchronous); am_ff_download copies y [n, C] back and synchronises.
- * am_forward_ff = the three in sequence.  Replaces the FF branch of predict (predict_folds.py:69-94) and of
+ * am_forward_ff = upload, then the device path in 65,536-row chunks with the download of chunk c overlapping the
+ * compute of chunk c+1 on a separate stream (same results).  Replaces the FF branch of predict (predict_folds.py:69-94) and of
  * evaluateModelTestTri (evaluateModelForTest.py:98-112). */
 int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, int64_t n, int halo_lo, int halo_hi);
 int am_ff_run(am_pipeline* p);

@@ -37,6 +37,8 @@ SIGNATURES = {
     "am_profile_reset": (C.c_int, [C.c_void_p]),
     "am_profile_read": (C.c_int, [C.c_void_p, c_int64_p, C.POINTER(C.c_double)]),
     "am_kernel_name": (C.c_char_p, [C.c_int]),
+    "am_host_alloc": (C.c_int, [C.c_size_t, c_void_pp]),
+    "am_host_free": (C.c_int, [C.c_void_p]),
     "am_model_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p,
                                   C.POINTER(c_float_p), C.POINTER(c_float_p), C.POINTER(c_float_p), c_void_pp]),
     "am_model_destroy": (C.c_int, [C.c_void_p]),

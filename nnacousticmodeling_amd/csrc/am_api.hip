@@ -67,7 +67,7 @@ struct DevBuf {
 struct am_engine {
     int device = -1;
     hipStream_t stream = nullptr;    // compute stream: every GEMM / frontend / recurrent kernel
-    hipStream_t stream2 = nullptr;   // epilogue stream: the HBM-bound finish pass of chunk c overlaps the MFMA-bound GEMMs of chunk c+1
+    hipStream_t stream2 = nullptr;   // copy stream: D2H of chunk c overlaps the compute of chunk c+1 (am_forward_ff)
     hipEvent_t s2_tail = nullptr;    // last work enqueued on stream2
     bool s2_dirty = false;
     hipEvent_t ev[64] = {};
@@ -113,10 +113,8 @@ struct am_pipeline {
     int64_t n = 0;
     int halo_lo = 0, halo_hi = 0;
     bool has_ivec = false;
-    DevBuf d_x, d_ivec, d_in, d_act0, d_act1, d_acc, d_accB, d_acc2, d_out;
-    hipEvent_t acc_ready[2] = {}, fin_done[2] = {};  // logits buffer hand-off between the compute and epilogue streams
-    bool fin_pending[2] = {false, false};
-    uint64_t chunk_seq = 0;
+    DevBuf d_x, d_ivec, d_in, d_act0, d_act1, d_acc, d_acc2, d_out;
+    std::vector<hipEvent_t> chunk_done;  // one-shot path: chunk c's posteriors are final (compute stream -> copy stream)
     // lstm
     DevBuf d_src, d_dst, d_G, d_H0, d_H1, d_c;
     std::vector<int64_t> step_off;
@@ -135,15 +133,16 @@ struct am_pipeline {
     }
 };
 
-// Rows per feed-forward chunk (bounds the activation workspace) and whether the finish pass runs on the epilogue stream.
-// Tunables for experiments: AM_FF_CHUNK_ROWS (multiple of 256), AM_FF_OVERLAP (0/1).
+// Rows per feed-forward chunk of the device-resident path (bounds the activation workspace); tunable for experiments.
 static int64_t env_int(const char* name, int64_t dflt)
 {
     const char* v = getenv(name);
     return v && *v ? atoll(v) : dflt;
 }
 static const int64_t FF_CHUNK_ROWS = std::max<int64_t>(GEMM_BM, env_int("AM_FF_CHUNK_ROWS", 1 << 18) / GEMM_BM * GEMM_BM);
-static const bool FF_OVERLAP = env_int("AM_FF_OVERLAP", 0) != 0;
+// chunk of the one-shot host-to-host call: 65,536 rows = 256 row tiles, whole rounds of 256 blocks for 4-, 5- and 8-tile
+// wide layers (one chunk-sized launch costs ~2 % more than one launch over 196,608 rows)
+static const int64_t FF_PIPE_ROWS = std::max<int64_t>(GEMM_BM, env_int("AM_FF_PIPE_ROWS", 1 << 16) / GEMM_BM * GEMM_BM);
 
 // ----------------------------------------------------------------------------------------------------
 // kernel launch with optional event bracketing
@@ -169,7 +168,7 @@ static int run_kernel(am_engine* e, int id, F&& launch, hipStream_t on = nullptr
     return AM_OK;
 }
 
-// make the compute stream wait (on the device) for everything enqueued on the epilogue stream
+// make the compute stream wait (on the device) for everything enqueued on the copy stream
 static int join_streams(am_engine* e)
 {
     if (e->s2_dirty) { HIP_TRY(hipStreamWaitEvent(e->stream, e->s2_tail, 0)); e->s2_dirty = false; }
@@ -322,6 +321,21 @@ extern "C" int am_profile_read(am_engine* e, int64_t calls[AM_KERNEL_ID_MAX], do
     return AM_OK;
 }
 
+extern "C" int am_host_alloc(size_t bytes, void** out)
+{
+    if (!out) return fail(AM_EINVAL, "am_host_alloc: out is NULL");
+    *out = nullptr;
+    if (am_device_count() <= 0) return fail(AM_ENODEV, "no HIP device visible");
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocPortable));
+    return AM_OK;
+}
+
+extern "C" int am_host_free(void* ptr)
+{
+    if (ptr) HIP_TRY(hipHostFree(ptr));
+    return AM_OK;
+}
+
 // ----------------------------------------------------------------------------------------------------
 // models
 // ----------------------------------------------------------------------------------------------------
@@ -433,10 +447,10 @@ extern "C" int am_pipeline_destroy(am_pipeline* p)
     (void)hipSetDevice(p->e->device);
     (void)hipStreamSynchronize(p->e->stream);
     (void)hipStreamSynchronize(p->e->stream2);
-    for (int i = 0; i < 2; ++i) { if (p->acc_ready[i]) (void)hipEventDestroy(p->acc_ready[i]); if (p->fin_done[i]) (void)hipEventDestroy(p->fin_done[i]); }
+    for (auto ev : p->chunk_done) (void)hipEventDestroy(ev);
     p->drop_graph();
     for (DevBuf* d : {&p->d_shifts, &p->d_add, &p->d_scale, &p->d_rplw, &p->d_rplb, &p->d_rpllb, &p->d_prior, &p->d_x, &p->d_ivec, &p->d_in,
-                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_accB, &p->d_acc2, &p->d_out, &p->d_src, &p->d_dst, &p->d_G, &p->d_H0, &p->d_H1, &p->d_c})
+                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_src, &p->d_dst, &p->d_G, &p->d_H0, &p->d_H1, &p->d_c})
         d->release();
     delete p;
     return AM_OK;
@@ -595,7 +609,7 @@ extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, i
     am_model* m0 = p->members[0];
     const int64_t ext = halo_lo + n + halo_hi;
     if (n > 0 && ext <= 0) return fail(AM_EINVAL, "am_ff_upload: empty input");
-    const int64_t rows = std::min<int64_t>(round_up(std::max<int64_t>(n, 1), GEMM_BM), FF_CHUNK_ROWS);
+    const int64_t rows = std::min<int64_t>(round_up(std::max<int64_t>(n, 1), GEMM_BM), std::max(FF_CHUNK_ROWS, FF_PIPE_ROWS));
     int width = 0;
     for (auto* m : p->members) width = std::max(width, m->max_width);
     AM_TRY(p->d_x.ensure(std::max<size_t>(sizeof(float) * ext * p->D, 16)));
@@ -610,7 +624,6 @@ extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, i
         AM_TRY(p->d_act1.ensure(sizeof(float) * rows * width));
     }
     AM_TRY(p->d_acc.ensure(sizeof(float) * rows * m0->C_pad));
-    AM_TRY(p->d_accB.ensure(sizeof(float) * rows * m0->C_pad));
     if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(p->d_acc2.ensure(sizeof(float) * rows * m0->C_pad));
     AM_TRY(p->d_out.ensure(std::max<size_t>(sizeof(float) * n * m0->C, 16)));
     AM_TRY(sync_all(e));
@@ -644,14 +657,16 @@ static int ff_member_forward(am_pipeline* p, int mi, int64_t rows_pad, float* ac
     return AM_OK;
 }
 
-extern "C" int am_ff_run(am_pipeline* p)
+// One pass over the resident shard in chunks of `chunk_rows`.  With `host_y` the posteriors of chunk c are copied back on
+// the copy stream while the compute stream works on chunk c+1 (all compute is enqueued first, then the copies, so the
+// overlap also holds for pageable host memory, where hipMemcpyAsync blocks the calling thread).
+static int ff_run_chunks(am_pipeline* p, int64_t chunk_rows, float* host_y)
 {
-    if (!p || p->mode != 1) return fail(AM_EINVAL, "am_ff_run: nothing uploaded (am_ff_upload)");
     am_engine* e = p->e;
-    HIP_TRY(hipSetDevice(e->device));
     am_model* m0 = p->members[0];
-    for (int64_t c0 = 0; c0 < p->n; c0 += FF_CHUNK_ROWS) {
-        const int64_t nc = std::min<int64_t>(FF_CHUNK_ROWS, p->n - c0);
+    size_t n_chunks = 0;
+    for (int64_t c0 = 0; c0 < p->n; c0 += chunk_rows, ++n_chunks) {
+        const int64_t nc = std::min<int64_t>(chunk_rows, p->n - c0);
         const int64_t nc_pad = round_up(nc, GEMM_BM);
         SpliceArgs s{};
         s.x = p->d_x.as<float>(); s.ext_rows = p->halo_lo + p->n + p->halo_hi; s.first = p->halo_lo + c0;
@@ -660,32 +675,38 @@ extern "C" int am_ff_run(am_pipeline* p)
         s.add = p->has_ft ? p->d_add.as<float>() : nullptr; s.scale = p->has_ft ? p->d_scale.as<float>() : nullptr;
         s.d_iv = p->d_iv; s.out = p->d_in.as<float>(); s.ldo = m0->in_pad;
         AM_TRY(run_kernel(e, K_SPLICE_FT, [&] { return launch_splice_ft(e->stream, s); }));
-        // The finish pass (HBM-bound) of this chunk runs on the epilogue stream and overlaps the MFMA-bound GEMMs of the
-        // next chunk / next run; the logits buffer is double-buffered and handed over with events.
-        const bool overlap = FF_OVERLAP && p->combine == AM_COMBINE_LOGITS;
-        const int par = overlap ? (int)(p->chunk_seq++ & 1) : 0;
-        float* acc = (par ? p->d_accB : p->d_acc).as<float>();
-        if (overlap && p->fin_pending[par]) {   // the finish pass that last read this buffer must be done before it is overwritten
-            HIP_TRY(hipStreamWaitEvent(e->stream, p->fin_done[par], 0));
-            p->fin_pending[par] = false;
-        }
         for (int mi = 0; mi < (int)p->members.size(); ++mi) {
-            AM_TRY(ff_member_forward(p, mi, nc_pad, acc));
+            AM_TRY(ff_member_forward(p, mi, nc_pad, p->d_acc.as<float>()));
             if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(member_finish(p, mi, nc));
         }
-        float* out = p->d_out.as<float>() + c0 * m0->C;
-        if (!overlap) { AM_TRY(final_finish(p, nc, out, nullptr)); continue; }
-        for (hipEvent_t* ev : {&p->acc_ready[par], &p->fin_done[par]})
-            if (!*ev) HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(p->acc_ready[par], e->stream));
-        HIP_TRY(hipStreamWaitEvent(e->stream2, p->acc_ready[par], 0));
-        AM_TRY(final_finish(p, nc, out, nullptr, acc, e->stream2));
-        HIP_TRY(hipEventRecord(p->fin_done[par], e->stream2));
+        AM_TRY(final_finish(p, nc, p->d_out.as<float>() + c0 * m0->C, nullptr));
+        if (host_y) {
+            if (p->chunk_done.size() <= n_chunks) {
+                hipEvent_t ev;
+                HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                p->chunk_done.push_back(ev);
+            }
+            HIP_TRY(hipEventRecord(p->chunk_done[n_chunks], e->stream));
+        }
+    }
+    if (host_y) {
+        size_t c = 0;
+        for (int64_t c0 = 0; c0 < p->n; c0 += chunk_rows, ++c) {
+            const int64_t nc = std::min<int64_t>(chunk_rows, p->n - c0);
+            HIP_TRY(hipStreamWaitEvent(e->stream2, p->chunk_done[c], 0));
+            HIP_TRY(hipMemcpyAsync(host_y + c0 * m0->C, p->d_out.as<float>() + c0 * m0->C, sizeof(float) * nc * m0->C, hipMemcpyDeviceToHost, e->stream2));
+        }
         HIP_TRY(hipEventRecord(e->s2_tail, e->stream2));
-        p->fin_pending[par] = true;
         e->s2_dirty = true;
     }
     return AM_OK;
+}
+
+extern "C" int am_ff_run(am_pipeline* p)
+{
+    if (!p || p->mode != 1) return fail(AM_EINVAL, "am_ff_run: nothing uploaded (am_ff_upload)");
+    HIP_TRY(hipSetDevice(p->e->device));
+    return ff_run_chunks(p, FF_CHUNK_ROWS, nullptr);
 }
 
 extern "C" int am_ff_download(am_pipeline* p, float* y)
@@ -702,8 +723,9 @@ extern "C" int am_ff_download(am_pipeline* p, float* y)
 extern "C" int am_forward_ff(am_pipeline* p, const float* x, const float* ivec, int64_t n, int halo_lo, int halo_hi, float* y)
 {
     AM_TRY(am_ff_upload(p, x, ivec, n, halo_lo, halo_hi));
-    AM_TRY(am_ff_run(p));
-    return am_ff_download(p, y);
+    if (!y) return fail(AM_EINVAL, "am_forward_ff: y is NULL");
+    AM_TRY(ff_run_chunks(p, FF_PIPE_ROWS, y));   // download of chunk c overlaps the compute of chunk c+1
+    return sync_all(p->e);
 }
 
 // ----------------------------------------------------------------------------------------------------

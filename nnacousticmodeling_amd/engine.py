@@ -27,6 +27,31 @@ def device_count():
     return int(_lib.load().am_device_count())
 
 
+class _Pinned:
+    """Owner of one am_host_alloc block, exported through the array interface (numpy keeps it alive as .base)."""
+
+    def __init__(self, shape, dtype):
+        self._lib = _lib.load()
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        ptr = C.c_void_p()
+        check(self._lib.am_host_alloc(nbytes, C.byref(ptr)))
+        self._ptr = ptr
+        self.__array_interface__ = {"data": (ptr.value, False), "shape": tuple(int(s) for s in shape), "typestr": dtype.str, "version": 3}
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                self._lib.am_host_free(self._ptr)
+                self._ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float32):
+    return np.asarray(_Pinned(shape, dtype))
+
+
 class Engine:
     """One MI355X: compute stream, events, workspace.  Raises AmError when the device is not a gfx950 GPU."""
 
@@ -82,6 +107,10 @@ class Engine:
             if nm is not None and calls[i]:
                 out[nm.decode()] = (int(calls[i]), float(ms[i]))
         return out
+
+    def pinned_empty(self, shape, dtype=np.float32):
+        """numpy array on page-locked host memory (am_host_alloc): downloads into it run at PCIe line rate."""
+        return pinned_empty(shape, dtype)
 
     # stand-alone stage entry points --------------------------------------------------------------
     def lognormalise(self, lp, ap=None):
@@ -252,10 +281,17 @@ class Pipeline:
         return y
 
     def forward_ff(self, x_ext, ivec=None, n=None, halo_lo=0, halo_hi=0, out=None):
+        """Host array in, host array out (am_forward_ff): the download of chunk c overlaps the compute of chunk c+1."""
+        x_ext = _f32(x_ext)
+        iv = None if ivec is None else _f32(ivec)
         n = x_ext.shape[0] - halo_lo - halo_hi if n is None else n
-        self.ff_upload(x_ext, ivec, n, halo_lo, halo_hi)
-        self.ff_run()
-        return self.ff_download(out)
+        if x_ext.shape != (halo_lo + n + halo_hi, self.D):
+            raise ValueError("x must be [halo_lo + n + halo_hi, D]")
+        y = out if out is not None else np.empty((n, self.num_classes), dtype=np.float32)
+        assert y.dtype == np.float32 and y.flags.c_contiguous and y.shape == (n, self.num_classes)
+        check(self._lib.am_forward_ff(self._h, _fp(x_ext), _fp(iv), int(n), int(halo_lo), int(halo_hi), _fp(y)))
+        self._n = int(n)
+        return y
 
     # recurrent -------------------------------------------------------------------------------------
     def lstm_upload(self, x, ivec, offsets, timedelay=0):

@@ -76,6 +76,22 @@ def main():
             fl = 2 * ((440 + d_iv) * units + (layers - 1) * units * units + units * 1909)
             report(name, n, wall, ms, calls, fl)
             p.close()
+    if args.which in ("all", "e2e"):
+        # host-to-host (PCIe-inclusive) rate of the headline model: pageable vs pinned output, one-shot call
+        params = orc.make_mlp_params(rng, 440, 1024, 4, 1909)
+        n = 196608
+        xx = rng.standard_normal((n, 40)).astype(np.float32)
+        p = Pipeline(eng)
+        p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+        p.set_members([Model(eng, "ff", 4, params)])
+        for label, out in (("pageable", np.empty((n, 1909), np.float32)), ("pinned", eng.pinned_empty((n, 1909)))):
+            p.forward_ff(xx, out=out)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                p.forward_ff(xx, out=out)
+            dt = (time.perf_counter() - t0) / 3
+            print(json.dumps({"config": "4x1024 N=196608 host-to-host (%s output)" % label, "ms_per_pass": round(dt * 1e3, 2), "frames_per_s": round(n / dt)}), flush=True)
+        p.close()
     if args.which in ("all", "lstm"):
         params = orc.make_lstm_params(rng, 40, 512, 3, 1909)
         m = Model(eng, "lstm", 3, params)
