@@ -158,6 +158,28 @@ int am_lognormalise(am_engine* e, float* lp, int64_t n, int c, const float* ap);
 int am_linear(am_engine* e, const float* x, int64_t n, int in_dim, const float* W, const float* b, int out_dim,
               int act, float* y);
 
+/* ---- Viterbi phone decoder (consumer of surface A) ------------------------------------------------- */
+/* replaces the PhoneRecog subprocess (evaluateModelForTest.py:124-127): CPhoneRecog::Init / RecogOne
+ * (recog_src/source/phone_recog.cpp:84-136, 138-254), one workgroup per utterance (main.cpp:51 parallelises over
+ * utterances with OpenMP).  The arrays are the fields of the decoding-graph image (kaldiTri1909.img) in file order;
+ * lm is scaled by LMW here (phone_recog.cpp:112); PIP is added to every triphone entry (callers pass -abs(PIP)).
+ * Segmentations are bit-identical to the reference: same float adds, same strict comparisons. */
+typedef struct am_decoder am_decoder;
+int am_decoder_create(am_engine* e, int numPhones, int numBiphones, int numTriphones, int numStates,
+                      const int* startIdxs, const int* endIdxs, const int* biphoneIdxIn, const int* stateIdxs,
+                      const float* tpSelfloop, const float* tpTransition, const int* outOffsets, const int* outValues,
+                      const float* lm, float PIP, float LMW, am_decoder** out);
+int am_decoder_destroy(am_decoder* d);
+/* lp: [offsets[n_utts], numStates] log-probabilities (what the .lab files hold), utterance u = rows
+ * [offsets[u], offsets[u+1]).  Output: utterance u's segments in time order at index offsets[u] .. offsets[u] +
+ * seg_count[u] - 1 of seg_begin / seg_end (frames, as written to the MLF) / seg_tri (triphone id -> phone table).
+ * Utterances that cannot reach a triphone exit (< 3 frames), for which the reference never terminates, get 0 segments. */
+int am_decode_host(am_decoder* d, const float* lp, const int64_t* offsets, int n_utts,
+                   int* seg_begin, int* seg_end, int* seg_tri, int* seg_count);
+/* Same, on the posteriors a pipeline has just produced, without leaving the GPU (no .lab round trip). */
+int am_decode_pipeline(am_decoder* d, am_pipeline* p, const int64_t* offsets, int n_utts,
+                       int* seg_begin, int* seg_end, int* seg_tri, int* seg_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,11 @@ SIGNATURES = {
     "am_pipeline_output_shape": (C.c_int, [C.c_void_p, c_int64_p, c_int_p]),
     "am_frontend_apply": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int64, C.c_int, C.c_int, c_float_p]),
     "am_lognormalise": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, C.c_int, c_float_p]),
+    "am_decoder_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p, c_float_p, c_float_p,
+                                    c_int_p, c_int_p, c_float_p, C.c_float, C.c_float, c_void_pp]),
+    "am_decoder_destroy": (C.c_int, [C.c_void_p]),
+    "am_decode_host": (C.c_int, [C.c_void_p, c_float_p, c_int64_p, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]),
+    "am_decode_pipeline": (C.c_int, [C.c_void_p, C.c_void_p, c_int64_p, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]),
     "am_linear": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, C.c_int, c_float_p, c_float_p, C.c_int, C.c_int, c_float_p]),
 }
 

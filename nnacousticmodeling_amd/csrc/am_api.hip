@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -214,7 +215,7 @@ extern "C" const char* am_version(void) { return "amfwd 0.1 (gfx950)"; }
 
 extern "C" const char* am_kernel_name(int id)
 {
-    static const char* names[K_COUNT] = {"splice_ft", "gemm_hidden", "gemm_out", "finish", "gather_ft", "lstm_upward", "lstm_step"};
+    static const char* names[K_COUNT] = {"splice_ft", "gemm_hidden", "gemm_out", "finish", "gather_ft", "lstm_upward", "lstm_step", "viterbi"};
     return (id >= 0 && id < K_COUNT) ? names[id] : nullptr;
 }
 
@@ -1001,4 +1002,152 @@ extern "C" int am_linear(am_engine* e, const float* x, int64_t n, int in_dim, co
     HIP_TRY(hipMemcpy2DAsync(y, sizeof(float) * out_dim, e->scratch[3].p, sizeof(float) * np, sizeof(float) * out_dim, n, hipMemcpyDeviceToHost, e->stream));
     AM_TRY(sync_all(e));
     return AM_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Viterbi phone decoder
+// ----------------------------------------------------------------------------------------------------
+struct am_decoder {
+    am_engine* e = nullptr;
+    int P = 0, B = 0, T = 0, S = 0;
+    float PIP = 0.f;
+    DevBuf endIdx, binIn, state, tpSelf, tpTrans, outOff, outVal, lm, p0;
+    DevBuf d_lp, d_off, pp, tt, p, bestI, bestT, seg_begin, seg_end, seg_tri, seg_count;
+};
+
+template <class Tt>
+static int upload_raw(am_engine* e, DevBuf& d, const Tt* src, size_t count)
+{
+    AM_TRY(d.ensure(std::max<size_t>(sizeof(Tt) * count, 16)));
+    if (count) HIP_TRY(hipMemcpyAsync(d.p, src, sizeof(Tt) * count, hipMemcpyHostToDevice, e->stream));
+    return AM_OK;
+}
+
+extern "C" int am_decoder_create(am_engine* e, int numPhones, int numBiphones, int numTriphones, int numStates,
+                                 const int* startIdxs, const int* endIdxs, const int* biphoneIdxIn, const int* stateIdxs,
+                                 const float* tpSelfloop, const float* tpTransition, const int* outOffsets, const int* outValues,
+                                 const float* lm, float PIP, float LMW, am_decoder** out)
+{
+    if (!out) return fail(AM_EINVAL, "am_decoder_create: out is NULL");
+    *out = nullptr;
+    if (!e || numPhones <= 0 || numBiphones <= 0 || numTriphones <= 0 || numStates <= 0 || !startIdxs || !endIdxs || !biphoneIdxIn ||
+        !stateIdxs || !tpSelfloop || !tpTransition || !outOffsets || !outValues || !lm)
+        return fail(AM_EINVAL, "am_decoder_create: bad argument");
+    const int P = numPhones, B = numBiphones, T = numTriphones;
+    // validate every index once on the host: the kernel then needs no bounds checks
+    for (int i = 0; i < P; ++i)
+        if (startIdxs[i] < 0 || startIdxs[i] >= B || endIdxs[i] < 0 || endIdxs[i] >= B) return fail(AM_EINVAL, "am_decoder_create: start/end node out of range");
+    for (int n = 0; n < T; ++n) {
+        if (biphoneIdxIn[n] < 0 || biphoneIdxIn[n] >= B) return fail(AM_EINVAL, "am_decoder_create: biphoneIdxIn[%d] out of range", n);
+        for (int s3 = 0; s3 < 3; ++s3)
+            if (stateIdxs[3 * n + s3] < 0 || stateIdxs[3 * n + s3] >= numStates) return fail(AM_EINVAL, "am_decoder_create: stateIdxs[%d] out of range", 3 * n + s3);
+    }
+    if (outOffsets[0] != 0) return fail(AM_EINVAL, "am_decoder_create: outOffsets[0] must be 0");
+    for (int i = 0; i < B; ++i)
+        if (outOffsets[i + 1] < outOffsets[i]) return fail(AM_EINVAL, "am_decoder_create: outOffsets must be non-decreasing");
+    for (int i = 0; i < outOffsets[B]; ++i)
+        if (outValues[i] < 0 || outValues[i] >= T) return fail(AM_EINVAL, "am_decoder_create: outValues[%d] out of range", i);
+    HIP_TRY(hipSetDevice(e->device));
+    am_decoder* d = new am_decoder();
+    d->e = e; d->P = P; d->B = B; d->T = T; d->S = numStates; d->PIP = PIP;
+    std::vector<float> lms(B), p0(B, -1e20f);
+    for (int i = 0; i < B; ++i) lms[i] = lm[i] * LMW;                                     // phone_recog.cpp:112
+    for (int i = 0; i < P; ++i) p0[startIdxs[i]] = (float)((double)lms[startIdxs[i]] - log((double)(float)P));  // phone_recog.cpp:148
+    int rc = AM_OK;
+    if ((rc = upload_raw(e, d->endIdx, endIdxs, P)) == AM_OK && (rc = upload_raw(e, d->binIn, biphoneIdxIn, T)) == AM_OK &&
+        (rc = upload_raw(e, d->state, stateIdxs, 3 * (size_t)T)) == AM_OK && (rc = upload_raw(e, d->tpSelf, tpSelfloop, 3 * (size_t)T)) == AM_OK &&
+        (rc = upload_raw(e, d->tpTrans, tpTransition, 3 * (size_t)T)) == AM_OK && (rc = upload_raw(e, d->outOff, outOffsets, (size_t)B + 1)) == AM_OK &&
+        (rc = upload_raw(e, d->outVal, outValues, (size_t)outOffsets[B])) == AM_OK && (rc = upload_raw(e, d->lm, lms.data(), B)) == AM_OK &&
+        (rc = upload_raw(e, d->p0, p0.data(), B)) == AM_OK)
+        rc = sync_all(e);
+    if (rc != AM_OK) { am_decoder_destroy(d); return rc; }
+    *out = d;
+    return AM_OK;
+}
+
+extern "C" int am_decoder_destroy(am_decoder* d)
+{
+    if (!d) return AM_OK;
+    (void)hipSetDevice(d->e->device);
+    (void)hipStreamSynchronize(d->e->stream);
+    for (DevBuf* b : {&d->endIdx, &d->binIn, &d->state, &d->tpSelf, &d->tpTrans, &d->outOff, &d->outVal, &d->lm, &d->p0, &d->d_lp, &d->d_off,
+                      &d->pp, &d->tt, &d->p, &d->bestI, &d->bestT, &d->seg_begin, &d->seg_end, &d->seg_tri, &d->seg_count})
+        b->release();
+    delete d;
+    return AM_OK;
+}
+
+// decode posteriors already on the device (lp_dev [N, ld]); results to the host arrays, chronological per utterance
+static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const int64_t* offsets, int n_utts,
+                         int* seg_begin, int* seg_end, int* seg_tri, int* seg_count)
+{
+    am_engine* e = d->e;
+    const int64_t N = offsets[n_utts];
+    for (int u = 0; u < n_utts; ++u)
+        if (offsets[u + 1] < offsets[u]) return fail(AM_EINVAL, "am_decode: offsets must be non-decreasing");
+    if (N > INT32_MAX) return fail(AM_EINVAL, "am_decode: too many frames");
+    const size_t T3 = 3 * (size_t)d->T;
+    std::vector<long long> off(offsets, offsets + n_utts + 1);
+    AM_TRY(upload_raw(e, d->d_off, off.data(), off.size()));
+    AM_TRY(d->pp.ensure(sizeof(float) * T3 * n_utts));
+    AM_TRY(d->tt.ensure(sizeof(int) * T3 * n_utts));
+    AM_TRY(d->p.ensure(sizeof(float) * (size_t)d->B * n_utts));
+    AM_TRY(d->bestI.ensure(std::max<size_t>(sizeof(int) * (size_t)N * d->B, 16)));
+    AM_TRY(d->bestT.ensure(std::max<size_t>(sizeof(int) * (size_t)N * d->B, 16)));
+    for (DevBuf* b : {&d->seg_begin, &d->seg_end, &d->seg_tri}) AM_TRY(b->ensure(std::max<size_t>(sizeof(int) * (size_t)N, 16)));
+    AM_TRY(d->seg_count.ensure(sizeof(int) * std::max(n_utts, 1)));
+    ViterbiArgs a{};
+    a.P = d->P; a.B = d->B; a.T = d->T;
+    a.endIdx = d->endIdx.as<int>(); a.binIn = d->binIn.as<int>(); a.state = d->state.as<int>();
+    a.tpSelf = d->tpSelf.as<float>(); a.tpTrans = d->tpTrans.as<float>(); a.outOff = d->outOff.as<int>(); a.outVal = d->outVal.as<int>();
+    a.lm = d->lm.as<float>(); a.p0 = d->p0.as<float>(); a.PIP = d->PIP;
+    a.lp = lp_dev; a.ldl = ld; a.offsets = d->d_off.as<long long>();
+    a.pp = d->pp.as<float>(); a.tt = d->tt.as<int>(); a.p = d->p.as<float>(); a.bestI = d->bestI.as<int>(); a.bestT = d->bestT.as<int>();
+    a.seg_begin = d->seg_begin.as<int>(); a.seg_end = d->seg_end.as<int>(); a.seg_tri = d->seg_tri.as<int>(); a.seg_count = d->seg_count.as<int>();
+    AM_TRY(run_kernel(e, K_VITERBI, [&] { return launch_viterbi(e->stream, a, n_utts); }));
+    std::vector<int> hb(std::max<int64_t>(N, 1)), he(std::max<int64_t>(N, 1)), ht(std::max<int64_t>(N, 1));
+    if (N > 0) {
+        HIP_TRY(hipMemcpyAsync(hb.data(), d->seg_begin.p, sizeof(int) * N, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(he.data(), d->seg_end.p, sizeof(int) * N, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(ht.data(), d->seg_tri.p, sizeof(int) * N, hipMemcpyDeviceToHost, e->stream));
+    }
+    if (n_utts > 0) HIP_TRY(hipMemcpyAsync(seg_count, d->seg_count.p, sizeof(int) * n_utts, hipMemcpyDeviceToHost, e->stream));
+    AM_TRY(sync_all(e));
+    for (int u = 0; u < n_utts; ++u) {   // the kernel stores each utterance's segments last-to-first
+        const int64_t o = offsets[u];
+        const int c = seg_count[u];
+        for (int j = 0; j < c; ++j) {
+            seg_begin[o + j] = hb[o + c - 1 - j];
+            seg_end[o + j] = he[o + c - 1 - j];
+            seg_tri[o + j] = ht[o + c - 1 - j];
+        }
+    }
+    return AM_OK;
+}
+
+extern "C" int am_decode_host(am_decoder* d, const float* lp, const int64_t* offsets, int n_utts,
+                              int* seg_begin, int* seg_end, int* seg_tri, int* seg_count)
+{
+    if (!d || !offsets || n_utts < 0 || !seg_begin || !seg_end || !seg_tri || !seg_count || offsets[0] != 0) return fail(AM_EINVAL, "am_decode_host: bad argument");
+    const int64_t N = offsets[n_utts];
+    if (N > 0 && !lp) return fail(AM_EINVAL, "am_decode_host: lp is NULL");
+    am_engine* e = d->e;
+    HIP_TRY(hipSetDevice(e->device));
+    AM_TRY(sync_all(e));
+    AM_TRY(d->d_lp.ensure(std::max<size_t>(sizeof(float) * (size_t)N * d->S, 16)));
+    if (N > 0) HIP_TRY(hipMemcpyAsync(d->d_lp.p, lp, sizeof(float) * (size_t)N * d->S, hipMemcpyHostToDevice, e->stream));
+    return decode_device(d, d->d_lp.as<float>(), d->S, offsets, n_utts, seg_begin, seg_end, seg_tri, seg_count);
+}
+
+extern "C" int am_decode_pipeline(am_decoder* d, am_pipeline* p, const int64_t* offsets, int n_utts,
+                                  int* seg_begin, int* seg_end, int* seg_tri, int* seg_count)
+{
+    if (!d || !p || !offsets || n_utts < 0 || !seg_begin || !seg_end || !seg_tri || !seg_count || offsets[0] != 0) return fail(AM_EINVAL, "am_decode_pipeline: bad argument");
+    if (p->e != d->e) return fail(AM_EINVAL, "am_decode_pipeline: decoder and pipeline live on different engines");
+    if (p->mode == 0) return fail(AM_EINVAL, "am_decode_pipeline: the pipeline holds no posteriors (run it first)");
+    if (p->members[0]->C != d->S) return fail(AM_EINVAL, "Num states in log-probs file and model image differ!");
+    if (offsets[n_utts] != p->n) return fail(AM_EINVAL, "am_decode_pipeline: offsets cover %lld frames, the pipeline holds %lld", (long long)offsets[n_utts], (long long)p->n);
+    HIP_TRY(hipSetDevice(d->e->device));
+    AM_TRY(join_streams(d->e));
+    return decode_device(d, p->d_out.as<float>(), d->S, offsets, n_utts, seg_begin, seg_end, seg_tri, seg_count);
 }

@@ -13,8 +13,9 @@ enum KernelId {
     K_FINISH = 3,      // combine divide / RPL4 / prior / log-softmax
     K_GATHER_FT = 4,   // recurrent path: gather rows to time-major + transform
     K_LSTM_UPWARD = 5, // hoisted upward GEMM of an LSTM layer (MFMA f32)
-    K_LSTM_STEP = 6,   // one recurrent step: h W_lat^T + gates
-    K_COUNT = 7
+    K_LSTM_STEP = 6,   // one wavefront step of the LSTM stack
+    K_VITERBI = 7,     // triphone Viterbi decode, one workgroup per utterance
+    K_COUNT = 8
 };
 
 constexpr int GEMM_BM = 256;  // rows per block tile: every activation matrix is padded to a multiple of this
@@ -93,5 +94,24 @@ struct LstmWavefrontArgs {
     int ut_groups;       // set by the launcher
 };
 hipError_t launch_lstm_wavefront(hipStream_t s, LstmWavefrontArgs& a);
+
+struct ViterbiArgs {
+    int P, B, T;                       // phones (start/end nodes), biphone nodes, triphones
+    const int* endIdx;                 // [P]
+    const int* binIn;                  // [T]  node a triphone leaves from
+    const int* state;                  // [3T] posterior column of state s of triphone n at [3n+s]
+    const float* tpSelf; const float* tpTrans;   // [3T]
+    const int* outOff; const int* outVal;        // CSR: triphones arriving at each node
+    const float* lm;                   // [B] already scaled by LMW
+    const float* p0;                   // [B] initial node scores
+    float PIP;
+    const float* lp; long long ldl;    // log-probabilities [N, ldl]
+    const long long* offsets;          // [n_utts + 1] device
+    float* pp; int* tt; float* p;      // per-utterance scratch: [n_utts][3T], [n_utts][3T], [n_utts][B]
+    int* bestI; int* bestT;            // [N][B] back-pointers
+    int* seg_begin; int* seg_end; int* seg_tri;  // [N] segments of utterance u at [offsets[u], offsets[u] + seg_count[u]), last first
+    int* seg_count;                    // [n_utts]
+};
+hipError_t launch_viterbi(hipStream_t s, const ViterbiArgs& a, int n_utts);
 
 }  // namespace am

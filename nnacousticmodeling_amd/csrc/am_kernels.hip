@@ -618,4 +618,87 @@ hipError_t launch_lstm_wavefront(hipStream_t s, LstmWavefrontArgs& a)
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Triphone Viterbi decoder (consumer of surface A; reference recog_src/source/phone_recog.cpp:138-254).
+// One workgroup per utterance (the reference parallelises over utterances with OpenMP, main.cpp:51); inside a frame the
+// triphone updates are independent (each reads last frame's scores), then the per-node maxima over the arriving
+// triphones are independent; two barriers per frame.  Every score is one float add of two floats, compared with the
+// reference's strict inequalities (ties keep the stay branch / the first maximum), so segmentations are bit-identical.
+// The back-trace is bounded by the frame count: the reference's loop does not terminate for utterances that cannot reach
+// a triphone exit (fewer than 3 frames); such utterances yield zero segments here.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void viterbi_kernel(const ViterbiArgs a)
+{
+    const int u = blockIdx.x, tid = threadIdx.x;
+    const long long row0 = a.offsets[u];
+    const int N = (int)(a.offsets[u + 1] - row0);
+    const int T = a.T, B = a.B;
+    float* pp = a.pp + (size_t)u * 3 * T;
+    int* tt = a.tt + (size_t)u * 3 * T;
+    float* p = a.p + (size_t)u * B;
+    int* bI = a.bestI + (size_t)row0 * B;
+    int* bT = a.bestT + (size_t)row0 * B;
+    const float NINF = -1e20f;
+    for (int i = tid; i < B; i += 1024) p[i] = a.p0[i];
+    for (int i = tid; i < 3 * T; i += 1024) { pp[i] = NINF; tt[i] = 0; }
+    __syncthreads();
+    for (int k = 0; k < N; ++k) {
+        const float* lp1 = a.lp + (size_t)(row0 + k) * a.ldl;
+        for (int n = tid; n < T; n += 1024) {
+            const float pIn = p[a.binIn[n]] + a.PIP;
+            const float pp0 = pp[n], pp1 = pp[n + T], pp2 = pp[n + 2 * T];
+            const int t0 = tt[n], t1 = tt[n + T], t2 = tt[n + 2 * T];
+            const float st0 = pp0 + a.tpSelf[3 * n], st1 = pp1 + a.tpSelf[3 * n + 1], st2 = pp2 + a.tpSelf[3 * n + 2];
+            const float go0 = pIn, go1 = pp0 + a.tpTrans[3 * n], go2 = pp1 + a.tpTrans[3 * n + 1];
+            const float e0 = lp1[a.state[3 * n]], e1 = lp1[a.state[3 * n + 1]], e2 = lp1[a.state[3 * n + 2]];
+            if (go2 > st2) { pp[n + 2 * T] = go2 + e2; tt[n + 2 * T] = t1; } else { pp[n + 2 * T] = st2 + e2; tt[n + 2 * T] = t2; }
+            if (go1 > st1) { pp[n + T] = go1 + e1; tt[n + T] = t0; } else { pp[n + T] = st1 + e1; tt[n + T] = t1; }
+            if (go0 > st0) { pp[n] = go0 + e0; tt[n] = k - 1; } else { pp[n] = st0 + e0; tt[n] = t0; }
+        }
+        __syncthreads();
+        for (int i = tid; i < B; i += 1024) {
+            int mxi = 0;
+            float mx = NINF;
+            for (int s = a.outOff[i]; s < a.outOff[i + 1]; ++s) {
+                const int ids = a.outVal[s];
+                const float pOut = pp[ids + 2 * T] + a.tpTrans[3 * ids + 2];
+                if (mx < pOut) { mx = pOut; mxi = ids; }
+            }
+            p[i] = mx + a.lm[i];
+            bI[(size_t)k * B + i] = mxi;
+            bT[(size_t)k * B + i] = tt[mxi + 2 * T];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int mxi = 0;
+        float mx = NINF;
+        for (int i = 0; i < a.P; ++i) {
+            const int ids = a.endIdx[i];
+            if (mx < p[ids]) { mx = p[ids]; mxi = ids; }
+        }
+        int count = 0, t = N - 1;
+        bool ok = true;
+        while (t >= 0) {
+            if (count >= N) { ok = false; break; }       // the reference would loop forever here
+            const int id = bI[(size_t)t * B + mxi];
+            const int end = t + 1;
+            t = bT[(size_t)t * B + mxi];
+            a.seg_end[row0 + count] = end;
+            a.seg_begin[row0 + count] = t + 1;
+            a.seg_tri[row0 + count] = id;
+            mxi = a.binIn[id];
+            ++count;
+        }
+        a.seg_count[u] = ok ? count : 0;   // segments are stored last-to-first; the host reverses them
+    }
+}
+
+hipError_t launch_viterbi(hipStream_t s, const ViterbiArgs& a, int n_utts)
+{
+    if (n_utts <= 0) return hipSuccess;
+    hipLaunchKernelGGL(viterbi_kernel, dim3(n_utts), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
 }  // namespace am

@@ -57,6 +57,9 @@ def build_parser():
     parser.add_argument("--fold-network-pattern", default="fold_{0}.npz")
     parser.add_argument("--master-network", default="-", help="Master network")
     parser.add_argument("--tmp-dir", default="lab", help="where the .lab/.scp files go (the reference hard-codes 'lab')")
+    parser.add_argument("--decoder", default="auto", choices=["auto", "gpu", "subprocess", "none"],
+                        help="auto/gpu: in-process GPU Viterbi when <recog-dir>/kaldiTri1909.img exists; subprocess: the reference's PhoneRecog executable")
+    parser.add_argument("--no-lab", action="store_true", help="do not write the .lab/.scp posterior files (only the external executable needs them)")
     parser.add_argument("--no-progress", action="store_true", help="Disable progress bar")
     return parser
 
@@ -119,7 +122,8 @@ def main(arg_list=None):
     ap = args.ap_coef * np.load(str(Path(args.recog_dir, args.ap_file)))
     per = evaluateModelTestTri(model, data, offsets, args.PIP, args.LMW, ap=ap, testOrDev=args.test_or_dev, tmpDir=args.tmp_dir,
                                uttlistdir=args.utt_list_dir, recogdir=args.recog_dir, GPUID=devices, progress=not args.no_progress,
-                               rnn=recurrent, frontend=(shifts, ft), ivectors=ivectors)
+                               rnn=recurrent, frontend=(shifts, ft), ivectors=ivectors,
+                               run_decoder=(False if args.decoder == "none" else args.decoder), write_lab=not args.no_lab)
     print("PER: {0:.2f} %".format(per))
     return per
 

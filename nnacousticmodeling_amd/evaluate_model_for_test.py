@@ -51,13 +51,16 @@ def write_posteriors(y, offsets, testList, labDirOut, testOrDev):
 
 
 def evaluateModelTestTri(model, data, offsets, PIP, LMW, ap=None, GPUID=0, testOrDev="test", tmpDir="lab", uttlistdir=".",
-                         recogdir=".", progress=True, rnn=False, frontend=None, ivectors=None, run_decoder="auto"):
+                         recogdir=".", progress=True, rnn=False, frontend=None, ivectors=None, run_decoder="auto", write_lab=True):
     """Returns the PER (float); -1 when the utterance list and the offsets disagree, as the reference does.
 
     Differences from the reference, all on the host side: ``GPUID`` may be a list of device ids (negative = CPU is
     refused: no CPU fallback); ``frontend`` / ``ivectors`` select the fused on-GPU frontend (see
-    ``compute_posteriors``); ``run_decoder``: "auto" runs PhoneRecog only when the binary and ``kaldiTri1909.img``
-    exist under ``recogdir`` and otherwise stops after writing the posteriors, returning NaN."""
+    ``compute_posteriors``).  ``run_decoder``: "auto" / "gpu" decode in-process on the GPU (``phone_recog.PhoneRecog``,
+    same segmentations as the reference binary) when ``kaldiTri1909.img`` exists under ``recogdir``; "subprocess" runs the
+    reference's ``PhoneRecog`` executable as the reference does; without the graph image "auto" stops after writing the
+    posteriors and returns NaN.  ``write_lab=False`` skips the ``.lab``/``.scp`` files (442 MB for the core test set),
+    which only the external executable needs."""
     testList = open(uttlistdir + "/" + testOrDev + ".list").readlines()
     if len(testList) != len(offsets) - 1:
         print("Error: wrong number of utterances")
@@ -66,23 +69,37 @@ def evaluateModelTestTri(model, data, offsets, PIP, LMW, ap=None, GPUID=0, testO
     if progress:
         print("Calculating network outputs")
     y = compute_posteriors(model, data, offsets, ap=ap, devices=devices, rnn=rnn, frontend=frontend, ivectors=ivectors)
-    if progress:
-        print("Writing output files")
     labDirOut = Path(tmpDir)
-    scp = write_posteriors(y, np.asarray(offsets), testList, labDirOut, testOrDev)
+    labDirOut.mkdir(exist_ok=True, parents=True)
+    offsets = np.asarray(offsets)
+    scp = Path(labDirOut, testOrDev + ".scp")
+    if write_lab or run_decoder == "subprocess":
+        if progress:
+            print("Writing output files")
+        scp = write_posteriors(y, offsets, testList, labDirOut, testOrDev)
 
     recog = recogdir + "/PhoneRecog" + (".exe" if os.name == "nt" else "")
     img = str(Path(recogdir, "kaldiTri1909.img"))
-    have_decoder = os.path.isfile(recog) and os.path.isfile(img)
-    if run_decoder == "auto" and not have_decoder:
-        print("PhoneRecog or kaldiTri1909.img not found under %s: posteriors written to %s, decoding skipped" % (recogdir, scp))
-        return float("nan")
+    result_txt = str(Path(labDirOut, "vysledek_" + testOrDev + ".txt"))
     if not run_decoder:
         return float("nan")
+    if not os.path.isfile(img):
+        if run_decoder == "auto":
+            print("kaldiTri1909.img not found under %s: posteriors written to %s, decoding skipped" % (recogdir, scp))
+            return float("nan")
+        raise FileNotFoundError(img)
     from .scoring import computeWER, convert_results, loadMlf
-    result_txt = str(Path(labDirOut, "vysledek_" + testOrDev + ".txt"))
-    cmd = [recog, str(scp), img, result_txt, str(-abs(PIP)), str(LMW)]
-    subprocess.run(cmd, cwd=os.getcwd())
+    if run_decoder == "subprocess":
+        cmd = [recog, str(scp), img, result_txt, str(-abs(PIP)), str(LMW)]
+        subprocess.run(cmd, cwd=os.getcwd())
+    else:
+        from .phone_recog import PhoneRecog, base_name_copy, write_mlf
+        runner = get_runner(devices)
+        dec = PhoneRecog(runner._dev(devices[0]).engine, img, -abs(PIP), LMW)
+        results = dec.recognise(y, offsets)
+        names = [base_name_copy(str(Path(labDirOut, f.strip() + ".lab"))) for f in testList]
+        write_mlf(result_txt, names, results)
+        dec.close()
     p39 = str(Path(labDirOut, "vysledek_" + testOrDev + "_p39.txt"))
     convert_results(str(Path(recogdir, "phones.60-48-39.map")), result_txt, p39)
     ref = loadMlf(str(Path(recogdir, testOrDev + "_ref.mlf")))

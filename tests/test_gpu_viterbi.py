@@ -1,0 +1,121 @@
+"""GPU Viterbi decoder (row n1) through the C ABI: bit-identical segmentations to the reference decoder's golden vectors,
+to the numpy oracle on larger graphs, and end to end (posteriors decoded straight from device memory, PER scoring)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import am_oracle as orc
+from oracle import viterbi_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+def _logsoftmax(z):
+    return (z - np.log(np.sum(np.exp(z), axis=1, keepdims=True))).astype(np.float32)
+
+
+def test_segmentations_match_reference_golden(engine, golden_dir, tmp_path):
+    from nnacousticmodeling_amd.phone_recog import PhoneRecog
+    g = np.load(os.path.join(golden_dir, "viterbi.npz"))
+    for ci in range(int(g["n_cases"])):
+        PIP, LMW, n_utts = g["c%d_params" % ci]
+        path = tmp_path / ("g%d.img" % ci)
+        path.write_bytes(bytes(g["c%d_img" % ci]))
+        dec = PhoneRecog(engine, str(path), float(PIP), float(LMW))
+        lps = [g["c%d_u%d_lp" % (ci, u)] for u in range(int(n_utts))]
+        offsets = np.concatenate([[0], np.cumsum([lp.shape[0] for lp in lps])])
+        got = dec.recognise(np.concatenate(lps), offsets)
+        for u in range(int(n_utts)):
+            seg = g["c%d_u%d_seg" % (ci, u)]
+            phones = list(g["c%d_u%d_phones" % (ci, u)])
+            assert [(b, e) for b, e, _ in got[u]] == [(int(r[0]), int(r[1])) for r in seg]
+            assert [p for _, _, p in got[u]] == phones
+        dec.close()
+
+
+@pytest.mark.parametrize("P,S,PIP", [(12, 300, -4.0), (9, 1909, -20.0), (10, 128, 0.0)])
+def test_larger_graphs_match_oracle(engine, P, S, PIP):
+    from nnacousticmodeling_amd.phone_recog import PhoneRecog
+    rng = np.random.default_rng(P * 1000 + S)
+    graph = vo.make_graph(rng, P, S)
+    lens = [3, 40, 97, 5, 211]
+    lps = [_logsoftmax(4.0 * rng.standard_normal((n, S))) for n in lens]
+    offsets = np.concatenate([[0], np.cumsum(lens)])
+    dec = PhoneRecog(engine, dict(graph, numPhones=P, numBiphones=len(graph["lm"]), numTriphones=len(graph["biphoneIdxIn"])), PIP, 0.7)
+    got = dec.recognise(np.concatenate(lps), offsets)
+    for lp, segs in zip(lps, got):
+        want = [(b, e, graph["phones"][t]) for b, e, t in vo.recog_one(graph, lp, PIP, 0.7)]
+        assert segs == want
+    if vo.reference_available():  # the reference itself, when its build travelled to this box
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            vo.write_image(os.path.join(td, "g.img"), graph)
+            assert vo.reference_recog(os.path.join(td, "g.img"), lps, PIP, 0.7) == got
+    # utterances shorter than 3 frames (the reference never terminates on them): zero segments, the rest unaffected
+    short = dec.recognise(np.concatenate([lps[1][:2], lps[1]]), np.array([0, 2, 42]))
+    assert short[0] == [] and short[1] == got[1]
+    dec.close()
+
+
+def test_evaluate_end_to_end_with_gpu_decoder(engine, tmp_path, real_ft_path, real_priors):
+    """evaluate CLI on a synthetic 1909-state graph: posteriors -> in-process GPU Viterbi -> 60->39 map -> NIST PER."""
+    from nnacousticmodeling_amd import chainer_npz, evaluate, scoring
+    from nnacousticmodeling_amd.phone_recog import PhoneRecog
+    rng = np.random.default_rng(2024)
+    data_dir, recog_dir, lab_dir = tmp_path / "data", tmp_path / "recog", tmp_path / "lab"
+    data_dir.mkdir(), recog_dir.mkdir()
+    open(data_dir / "final.feature_transform", "w").write(open(real_ft_path).read())
+    np.save(recog_dir / "log_ap_Kaldi1909.npy", real_priors)
+    golden = os.path.dirname(real_ft_path)
+    open(recog_dir / "phones.60-48-39.map", "w").write(open(os.path.join(golden, "phones.60-48-39.map")).read())
+    phones60 = [l.split()[1] for l in open(os.path.join(golden, "phones.60-48-39.map")) if len(l.split()) == 3]
+    graph = vo.make_graph(rng, 8, 1909)
+    graph["phones"] = [phones60[int(p[1:]) * 7 % len(phones60)] for p in graph["phones"]]  # real 60-set labels
+    vo.write_image(str(recog_dir / "kaldiTri1909.img"), graph)
+    n_utts, n = 6, 700
+    off = orc.make_offsets(rng, n_utts, n, lo=40, hi=200)
+    x = rng.standard_normal((n, 40)).astype(np.float32)
+    np.save(data_dir / "data_test.npy", x)
+    np.save(data_dir / "offsets_test.npy", off)
+    names = ["SPK%d_SX%d" % (u, u) for u in range(n_utts)]
+    (data_dir / "test.list").write_text("".join(s + "\n" for s in names))
+    # reference transcriptions: perturb nothing -> use the decoder's own output of a first run as "truth" for utterance 0..2
+    params = orc.make_mlp_params(rng, 440, 128, 2, 1909)
+    chainer_npz.write_npz(tmp_path / "model", params)
+    base = ["-n", "ff", "-l", 2, "-u", 128, "--splice", 5, "--tri", "--data-dir", data_dir, "--offset-dir", data_dir, "--utt-list-dir", data_dir,
+            "--recog-dir", recog_dir, "-m", tmp_path / "model", "--tmp-dir", lab_dir, "--no-progress", "--PIP", 3, "--LMW", 0.5]
+    # first pass without a reference MLF present -> write a reference from the oracle decode of the oracle posteriors
+    ft = orc.load_kaldi_feature_transform(real_ft_path)
+    post = orc.evaluate_posteriors(orc.MLP(params, 2), orc.evaluate_frontend(x, 5, ft), off, ap=real_priors)
+    pmap = {l.split()[1]: l.split()[2] for l in open(os.path.join(golden, "phones.60-48-39.map")) if len(l.split()) == 3}
+    with open(recog_dir / "test_ref.mlf", "w") as f:
+        f.write("#!MLF!#\n")
+        for u in range(n_utts):
+            segs = vo.recog_one(graph, post[u], -3.0, 0.5)
+            words = [pmap[graph["phones"][t]] for _, _, t in segs]
+            if u % 2:
+                words = words[:-1] + ["sil"]  # make some utterances imperfect
+            f.write('"*/%s.lab"\n%s\n.\n' % (names[u], "\n".join(words)))
+    per = evaluate.main(base)
+    assert per is not None and 0.0 <= per < 100.0
+    # the MLF the GPU decoder wrote == oracle Viterbi on the posteriors the GPU wrote to the .lab files (bit-identical paths)
+    from nnacousticmodeling_amd.kw_io import loadBin
+    got = scoring.loadMlf(str(lab_dir / "vysledek_test.txt"))
+    for u in range(n_utts):
+        lp = loadBin(str(lab_dir / (names[u] + ".lab")))
+        want = vo.recog_one(graph, lp, -3.0, 0.5)
+        assert got[names[u]][0] == [graph["phones"][t] for _, _, t in want]
+        assert got[names[u]][1] == [b * 100000 for b, _, _ in want] and got[names[u]][2] == [e * 100000 for _, e, _ in want]
+    want_per = scoring.computeWER(scoring.loadMlf(str(lab_dir / "vysledek_test_p39.txt")), scoring.loadMlf(str(recog_dir / "test_ref.mlf")), True)
+    assert per == want_per
+    # decoding straight from device memory gives the same segmentation as decoding the downloaded posteriors
+    from nnacousticmodeling_amd.engine import Model, Pipeline
+    p = Pipeline(engine)
+    p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+    p.set_members([Model(engine, "ff", 2, params)])
+    p.set_prior(real_priors)
+    y = p.forward_ff(x)
+    dec = PhoneRecog(engine, str(recog_dir / "kaldiTri1909.img"), -3.0, 0.5)
+    assert dec.recognise_pipeline(p, off) == dec.recognise(y, off)
+    dec.close()
