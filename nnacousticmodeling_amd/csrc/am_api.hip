@@ -1011,8 +1011,8 @@ struct am_decoder {
     am_engine* e = nullptr;
     int P = 0, B = 0, T = 0, S = 0;
     float PIP = 0.f;
-    DevBuf endIdx, binIn, state, tpSelf, tpTrans, outOff, outVal, lm, p0;
-    DevBuf d_lp, d_off, pp, tt, p, bestI, bestT, seg_begin, seg_end, seg_tri, seg_count;
+    DevBuf endIdx, tri_idx, tri_self, tri_trans, outOff, outVal, lm, p0;
+    DevBuf d_lp, d_off, pp, tt, pout, p, bestI, bestT, seg_begin, seg_end, seg_tri, seg_count;
 };
 
 template <class Tt>
@@ -1053,10 +1053,21 @@ extern "C" int am_decoder_create(am_engine* e, int numPhones, int numBiphones, i
     std::vector<float> lms(B), p0(B, -1e20f);
     for (int i = 0; i < B; ++i) lms[i] = lm[i] * LMW;                                     // phone_recog.cpp:112
     for (int i = 0; i < P; ++i) p0[startIdxs[i]] = (float)((double)lms[startIdxs[i]] - log((double)(float)P));  // phone_recog.cpp:148
+    // pack the per-triphone constants into 16-B records: one coalesced load each instead of eleven strided ones
+    std::vector<int> tidx(4 * (size_t)T);
+    std::vector<float> tself(4 * (size_t)T, 0.f), ttrans(4 * (size_t)T, 0.f);
+    for (int n = 0; n < T; ++n) {
+        tidx[4 * n] = biphoneIdxIn[n];
+        for (int s3 = 0; s3 < 3; ++s3) {
+            tidx[4 * n + 1 + s3] = stateIdxs[3 * n + s3];
+            tself[4 * n + s3] = tpSelfloop[3 * n + s3];
+            ttrans[4 * n + s3] = tpTransition[3 * n + s3];
+        }
+    }
     int rc = AM_OK;
-    if ((rc = upload_raw(e, d->endIdx, endIdxs, P)) == AM_OK && (rc = upload_raw(e, d->binIn, biphoneIdxIn, T)) == AM_OK &&
-        (rc = upload_raw(e, d->state, stateIdxs, 3 * (size_t)T)) == AM_OK && (rc = upload_raw(e, d->tpSelf, tpSelfloop, 3 * (size_t)T)) == AM_OK &&
-        (rc = upload_raw(e, d->tpTrans, tpTransition, 3 * (size_t)T)) == AM_OK && (rc = upload_raw(e, d->outOff, outOffsets, (size_t)B + 1)) == AM_OK &&
+    if ((rc = upload_raw(e, d->endIdx, endIdxs, P)) == AM_OK && (rc = upload_raw(e, d->tri_idx, tidx.data(), tidx.size())) == AM_OK &&
+        (rc = upload_raw(e, d->tri_self, tself.data(), tself.size())) == AM_OK && (rc = upload_raw(e, d->tri_trans, ttrans.data(), ttrans.size())) == AM_OK &&
+        (rc = upload_raw(e, d->outOff, outOffsets, (size_t)B + 1)) == AM_OK &&
         (rc = upload_raw(e, d->outVal, outValues, (size_t)outOffsets[B])) == AM_OK && (rc = upload_raw(e, d->lm, lms.data(), B)) == AM_OK &&
         (rc = upload_raw(e, d->p0, p0.data(), B)) == AM_OK)
         rc = sync_all(e);
@@ -1070,8 +1081,8 @@ extern "C" int am_decoder_destroy(am_decoder* d)
     if (!d) return AM_OK;
     (void)hipSetDevice(d->e->device);
     (void)hipStreamSynchronize(d->e->stream);
-    for (DevBuf* b : {&d->endIdx, &d->binIn, &d->state, &d->tpSelf, &d->tpTrans, &d->outOff, &d->outVal, &d->lm, &d->p0, &d->d_lp, &d->d_off,
-                      &d->pp, &d->tt, &d->p, &d->bestI, &d->bestT, &d->seg_begin, &d->seg_end, &d->seg_tri, &d->seg_count})
+    for (DevBuf* b : {&d->endIdx, &d->tri_idx, &d->tri_self, &d->tri_trans, &d->outOff, &d->outVal, &d->lm, &d->p0, &d->d_lp, &d->d_off,
+                      &d->pp, &d->tt, &d->pout, &d->p, &d->bestI, &d->bestT, &d->seg_begin, &d->seg_end, &d->seg_tri, &d->seg_count})
         b->release();
     delete d;
     return AM_OK;
@@ -1086,23 +1097,25 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
     for (int u = 0; u < n_utts; ++u)
         if (offsets[u + 1] < offsets[u]) return fail(AM_EINVAL, "am_decode: offsets must be non-decreasing");
     if (N > INT32_MAX) return fail(AM_EINVAL, "am_decode: too many frames");
-    const size_t T3 = 3 * (size_t)d->T;
+    const size_t T4 = 4 * (size_t)d->T;
     std::vector<long long> off(offsets, offsets + n_utts + 1);
     AM_TRY(upload_raw(e, d->d_off, off.data(), off.size()));
-    AM_TRY(d->pp.ensure(sizeof(float) * T3 * n_utts));
-    AM_TRY(d->tt.ensure(sizeof(int) * T3 * n_utts));
-    AM_TRY(d->p.ensure(sizeof(float) * (size_t)d->B * n_utts));
+    AM_TRY(d->pp.ensure(sizeof(float) * T4 * std::max(n_utts, 1)));
+    AM_TRY(d->tt.ensure(sizeof(int) * T4 * std::max(n_utts, 1)));
+    AM_TRY(d->pout.ensure(sizeof(float) * (size_t)d->T * std::max(n_utts, 1)));
+    AM_TRY(d->p.ensure(sizeof(float) * (size_t)d->B * std::max(n_utts, 1)));
     AM_TRY(d->bestI.ensure(std::max<size_t>(sizeof(int) * (size_t)N * d->B, 16)));
     AM_TRY(d->bestT.ensure(std::max<size_t>(sizeof(int) * (size_t)N * d->B, 16)));
     for (DevBuf* b : {&d->seg_begin, &d->seg_end, &d->seg_tri}) AM_TRY(b->ensure(std::max<size_t>(sizeof(int) * (size_t)N, 16)));
     AM_TRY(d->seg_count.ensure(sizeof(int) * std::max(n_utts, 1)));
     ViterbiArgs a{};
     a.P = d->P; a.B = d->B; a.T = d->T;
-    a.endIdx = d->endIdx.as<int>(); a.binIn = d->binIn.as<int>(); a.state = d->state.as<int>();
-    a.tpSelf = d->tpSelf.as<float>(); a.tpTrans = d->tpTrans.as<float>(); a.outOff = d->outOff.as<int>(); a.outVal = d->outVal.as<int>();
+    a.endIdx = d->endIdx.as<int>();
+    a.tri_idx = (decltype(a.tri_idx))d->tri_idx.p; a.tri_self = (decltype(a.tri_self))d->tri_self.p; a.tri_trans = (decltype(a.tri_trans))d->tri_trans.p;
+    a.outOff = d->outOff.as<int>(); a.outVal = d->outVal.as<int>();
     a.lm = d->lm.as<float>(); a.p0 = d->p0.as<float>(); a.PIP = d->PIP;
     a.lp = lp_dev; a.ldl = ld; a.offsets = d->d_off.as<long long>();
-    a.pp = d->pp.as<float>(); a.tt = d->tt.as<int>(); a.p = d->p.as<float>(); a.bestI = d->bestI.as<int>(); a.bestT = d->bestT.as<int>();
+    a.pp = d->pp.as<float>(); a.tt = d->tt.as<int>(); a.pout = d->pout.as<float>(); a.p = d->p.as<float>(); a.bestI = d->bestI.as<int>(); a.bestT = d->bestT.as<int>();
     a.seg_begin = d->seg_begin.as<int>(); a.seg_end = d->seg_end.as<int>(); a.seg_tri = d->seg_tri.as<int>(); a.seg_count = d->seg_count.as<int>();
     AM_TRY(run_kernel(e, K_VITERBI, [&] { return launch_viterbi(e->stream, a, n_utts); }));
     std::vector<int> hb(std::max<int64_t>(N, 1)), he(std::max<int64_t>(N, 1)), ht(std::max<int64_t>(N, 1));

@@ -98,16 +98,18 @@ hipError_t launch_lstm_wavefront(hipStream_t s, LstmWavefrontArgs& a);
 struct ViterbiArgs {
     int P, B, T;                       // phones (start/end nodes), biphone nodes, triphones
     const int* endIdx;                 // [P]
-    const int* binIn;                  // [T]  node a triphone leaves from
-    const int* state;                  // [3T] posterior column of state s of triphone n at [3n+s]
-    const float* tpSelf; const float* tpTrans;   // [3T]
+    // one 16-B record per triphone n (packed at load for coalesced access):
+    const __attribute__((ext_vector_type(4))) int* tri_idx;     // {node it leaves from, posterior column of state 0, 1, 2}
+    const __attribute__((ext_vector_type(4))) float* tri_self;  // {self-loop log-prob of state 0, 1, 2, 0}
+    const __attribute__((ext_vector_type(4))) float* tri_trans; // {transition log-prob of state 0, 1, 2, 0}
     const int* outOff; const int* outVal;        // CSR: triphones arriving at each node
     const float* lm;                   // [B] already scaled by LMW
     const float* p0;                   // [B] initial node scores
     float PIP;
     const float* lp; long long ldl;    // log-probabilities [N, ldl]
     const long long* offsets;          // [n_utts + 1] device
-    float* pp; int* tt; float* p;      // per-utterance scratch: [n_utts][3T], [n_utts][3T], [n_utts][B]
+    float* pp; int* tt;                // per-utterance state: [n_utts][T] x 16 B (3 state scores / 3 entry times)
+    float* pout; float* p;             // per-utterance: [n_utts][T] triphone exit scores, [n_utts][B] node scores
     int* bestI; int* bestT;            // [N][B] back-pointers
     int* seg_begin; int* seg_end; int* seg_tri;  // [N] segments of utterance u at [offsets[u], offsets[u] + seg_count[u]), last first
     int* seg_count;                    // [n_utts]

@@ -627,33 +627,44 @@ hipError_t launch_lstm_wavefront(hipStream_t s, LstmWavefrontArgs& a)
 // The back-trace is bounded by the frame count: the reference's loop does not terminate for utterances that cannot reach
 // a triphone exit (fewer than 3 frames); such utterances yield zero segments here.
 // ---------------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(1024) void viterbi_kernel(const ViterbiArgs a)
 {
     const int u = blockIdx.x, tid = threadIdx.x;
     const long long row0 = a.offsets[u];
     const int N = (int)(a.offsets[u + 1] - row0);
     const int T = a.T, B = a.B;
-    float* pp = a.pp + (size_t)u * 3 * T;
-    int* tt = a.tt + (size_t)u * 3 * T;
+    // per-utterance state, one 16-B record per triphone: scores of its 3 states / their entry times
+    f32x4* pp = (f32x4*)a.pp + (size_t)u * T;
+    i32x4* tt = (i32x4*)a.tt + (size_t)u * T;
+    float* pout = a.pout + (size_t)u * T;      // exit score of every triphone after this frame
     float* p = a.p + (size_t)u * B;
     int* bI = a.bestI + (size_t)row0 * B;
     int* bT = a.bestT + (size_t)row0 * B;
     const float NINF = -1e20f;
     for (int i = tid; i < B; i += 1024) p[i] = a.p0[i];
-    for (int i = tid; i < 3 * T; i += 1024) { pp[i] = NINF; tt[i] = 0; }
+    for (int i = tid; i < T; i += 1024) { pp[i] = (f32x4){NINF, NINF, NINF, 0.0f}; tt[i] = (i32x4){0, 0, 0, 0}; }
     __syncthreads();
     for (int k = 0; k < N; ++k) {
         const float* lp1 = a.lp + (size_t)(row0 + k) * a.ldl;
         for (int n = tid; n < T; n += 1024) {
-            const float pIn = p[a.binIn[n]] + a.PIP;
-            const float pp0 = pp[n], pp1 = pp[n + T], pp2 = pp[n + 2 * T];
-            const int t0 = tt[n], t1 = tt[n + T], t2 = tt[n + 2 * T];
-            const float st0 = pp0 + a.tpSelf[3 * n], st1 = pp1 + a.tpSelf[3 * n + 1], st2 = pp2 + a.tpSelf[3 * n + 2];
-            const float go0 = pIn, go1 = pp0 + a.tpTrans[3 * n], go2 = pp1 + a.tpTrans[3 * n + 1];
-            const float e0 = lp1[a.state[3 * n]], e1 = lp1[a.state[3 * n + 1]], e2 = lp1[a.state[3 * n + 2]];
-            if (go2 > st2) { pp[n + 2 * T] = go2 + e2; tt[n + 2 * T] = t1; } else { pp[n + 2 * T] = st2 + e2; tt[n + 2 * T] = t2; }
-            if (go1 > st1) { pp[n + T] = go1 + e1; tt[n + T] = t0; } else { pp[n + T] = st1 + e1; tt[n + T] = t1; }
-            if (go0 > st0) { pp[n] = go0 + e0; tt[n] = k - 1; } else { pp[n] = st0 + e0; tt[n] = t0; }
+            const i32x4 g = a.tri_idx[n];        // {node in, state 0, state 1, state 2}
+            const f32x4 sl = a.tri_self[n], tr = a.tri_trans[n];
+            const f32x4 q = pp[n];
+            const i32x4 t = tt[n];
+            const float pIn = p[g[0]] + a.PIP;
+            const float st0 = q[0] + sl[0], st1 = q[1] + sl[1], st2 = q[2] + sl[2];
+            const float go0 = pIn, go1 = q[0] + tr[0], go2 = q[1] + tr[1];
+            const float e0 = lp1[g[1]], e1 = lp1[g[2]], e2 = lp1[g[3]];
+            f32x4 nq; i32x4 nt;
+            if (go2 > st2) { nq[2] = go2 + e2; nt[2] = t[1]; } else { nq[2] = st2 + e2; nt[2] = t[2]; }
+            if (go1 > st1) { nq[1] = go1 + e1; nt[1] = t[0]; } else { nq[1] = st1 + e1; nt[1] = t[1]; }
+            if (go0 > st0) { nq[0] = go0 + e0; nt[0] = k - 1; } else { nq[0] = st0 + e0; nt[0] = t[0]; }
+            nq[3] = 0.0f; nt[3] = 0;
+            pp[n] = nq;
+            tt[n] = nt;
+            pout[n] = nq[2] + tr[2];
         }
         __syncthreads();
         for (int i = tid; i < B; i += 1024) {
@@ -661,12 +672,12 @@ __global__ __launch_bounds__(1024) void viterbi_kernel(const ViterbiArgs a)
             float mx = NINF;
             for (int s = a.outOff[i]; s < a.outOff[i + 1]; ++s) {
                 const int ids = a.outVal[s];
-                const float pOut = pp[ids + 2 * T] + a.tpTrans[3 * ids + 2];
+                const float pOut = pout[ids];
                 if (mx < pOut) { mx = pOut; mxi = ids; }
             }
             p[i] = mx + a.lm[i];
             bI[(size_t)k * B + i] = mxi;
-            bT[(size_t)k * B + i] = tt[mxi + 2 * T];
+            bT[(size_t)k * B + i] = tt[mxi][2];
         }
         __syncthreads();
     }
@@ -687,7 +698,7 @@ __global__ __launch_bounds__(1024) void viterbi_kernel(const ViterbiArgs a)
             a.seg_end[row0 + count] = end;
             a.seg_begin[row0 + count] = t + 1;
             a.seg_tri[row0 + count] = id;
-            mxi = a.binIn[id];
+            mxi = a.tri_idx[id][0];
             ++count;
         }
         a.seg_count[u] = ok ? count : 0;   // segments are stored last-to-first; the host reverses them

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof.sh <tag>   -- runs on the GPU box from the repo root; writes under gpurun_out/prof_<tag>/
+# usage: tools/prof.sh <tag>   -- runs on the GPU box from the repo root; writes under gpurun_out/prof_<tag>/
 set -o pipefail
 TAG=${1:-r1}
 OUT=gpurun_out/prof_$TAG

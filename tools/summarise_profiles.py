@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense a tools_prof.sh output directory (gpurun_out/prof_<tag>/) into the committed summaries under profiles/:
+"""Condense a tools/prof.sh output directory (gpurun_out/prof_<tag>/) into the committed summaries under profiles/:
 
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats table, verbatim
   profiles/<tag>_pmc_summary.json   per kernel (name + grid): launches, average duration and counter averages, plus
