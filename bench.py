@@ -109,7 +109,8 @@ def main():
     rank, local_rank, n_gpus = ranks.rank, ranks.local_rank, ranks.world
 
     ft, params, layers, x, iv, d_iv = make_workload(args.model, args.frames, rank)
-    eng = Engine(local_rank)
+    from nnacousticmodeling_amd.engine import device_count
+    eng = Engine(local_rank % max(device_count(), 1))  # one rank per GPU; wraps only when ranks outnumber the visible GPUs
     pipe = Pipeline(eng)
     pipe.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"], d_iv)
     pipe.set_members([Model(eng, "ff", layers, params)])
