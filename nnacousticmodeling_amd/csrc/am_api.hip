@@ -117,7 +117,7 @@ struct am_pipeline {
     DevBuf d_x, d_ivec, d_in, d_act0, d_act1, d_acc, d_acc2, d_out;
     std::vector<hipEvent_t> chunk_done;  // one-shot path: chunk c's posteriors are final (compute stream -> copy stream)
     // lstm
-    DevBuf d_src, d_dst, d_G, d_H0, d_H1, d_c;
+    DevBuf d_src, d_dst, d_G, d_H, d_c;   // d_H / d_c: one packed H plane and one cell-state array per layer
     std::vector<int64_t> step_off;
     std::vector<int> n_active;
     int64_t n_packed = 0;
@@ -451,7 +451,7 @@ extern "C" int am_pipeline_destroy(am_pipeline* p)
     for (auto ev : p->chunk_done) (void)hipEventDestroy(ev);
     p->drop_graph();
     for (DevBuf* d : {&p->d_shifts, &p->d_add, &p->d_scale, &p->d_rplw, &p->d_rplb, &p->d_rpllb, &p->d_prior, &p->d_x, &p->d_ivec, &p->d_in,
-                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_src, &p->d_dst, &p->d_G, &p->d_H0, &p->d_H1, &p->d_c})
+                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c})
         d->release();
     delete p;
     return AM_OK;
@@ -581,19 +581,18 @@ static int member_finish(am_pipeline* p, int mi, int64_t rows)
     return run_kernel(p->e, K_FINISH, [&] { return launch_finish(p->e->stream, f); });
 }
 
-static int final_finish(am_pipeline* p, int64_t rows, float* out, const int* row_map, const float* in = nullptr, hipStream_t on = nullptr)
+static int final_finish(am_pipeline* p, int64_t rows, float* out, const int* row_map)
 {
     am_model* m0 = p->members[0];
     FinishArgs f{};
-    f.in = in ? in : (p->combine == AM_COMBINE_LOGPOST ? p->d_acc2 : p->d_acc).as<float>(); f.ldin = m0->C_pad;
+    f.in = (p->combine == AM_COMBINE_LOGPOST ? p->d_acc2 : p->d_acc).as<float>(); f.ldin = m0->C_pad;
     f.out = out; f.ldout = m0->C; f.row_map = row_map;
     f.n = rows; f.C = m0->C;
     f.divisor = final_divisor(p);
     if (p->has_rpl) { f.rpl_w = p->d_rplw.as<float>(); f.rpl_b = p->d_rplb.as<float>(); f.rpl_lb = p->d_rpllb.as<float>(); }
     if (p->has_prior) f.prior = p->d_prior.as<float>();
     f.normalise = p->normalise;
-    hipStream_t st = on ? on : p->e->stream;
-    return run_kernel(p->e, K_FINISH, [&] { return launch_finish(st, f); }, st);
+    return run_kernel(p->e, K_FINISH, [&] { return launch_finish(p->e->stream, f); });
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -795,8 +794,8 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
     AM_TRY(p->d_G.ensure(sizeof(float) * rows_alloc * gw));
     int max_layers = 0;
     for (auto* m : p->members) max_layers = std::max(max_layers, m->n_layers);
-    AM_TRY(p->d_H0.ensure(sizeof(float) * rows_alloc * upad * max_layers));      // one H plane per layer
-    HIP_TRY(hipMemsetAsync(p->d_H0.p, 0, sizeof(float) * rows_alloc * upad * max_layers, e->stream));
+    AM_TRY(p->d_H.ensure(sizeof(float) * rows_alloc * upad * max_layers));      // one H plane per layer
+    HIP_TRY(hipMemsetAsync(p->d_H.p, 0, sizeof(float) * rows_alloc * upad * max_layers, e->stream));
     HIP_TRY(hipMemsetAsync(p->d_G.p, 0, sizeof(float) * rows_alloc * gw, e->stream));
     AM_TRY(p->d_c.ensure(sizeof(float) * (round_up(std::max(n_utts, 1), 16)) * upad * max_layers));
     AM_TRY(p->d_acc.ensure(sizeof(float) * rows_pad * m0->C_pad));
@@ -862,7 +861,7 @@ static int lstm_enqueue(am_pipeline* p)
             AM_TRY(run_kernel(e, K_LSTM_UPWARD, [&] { return launch_gemm(e->stream, g); }));
         }
         // wavefront over (layer, time): launch d runs layer l at t = d - l; chain length T + NL - 1 instead of T * NL
-        float* Hall = p->d_H0.as<float>();
+        float* Hall = p->d_H.as<float>();
         float* Call = p->d_c.as<float>();
         for (int64_t d = 0; d < T + NL - 1; ++d) {
             LstmWavefrontArgs w{};
