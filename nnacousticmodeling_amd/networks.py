@@ -8,7 +8,12 @@ from __future__ import annotations
 
 import numpy as np
 
-SUPPORTED = ("ff", "lstm")
+SUPPORTED = ("ff", "lstm", "zoneoutlstm", "zoneoutdropoutlstm")
+# At inference (chainer.config.train = False) zoneout returns the new state, so L.StatefulZoneoutLSTM computes exactly
+# what L.LSTM computes (upward Linear + bias-free lateral Linear, interleaved gates, h = None -> zeros on the first step)
+# and its npz keys are the same; both zoneout variants of the reference (chainer_networks.py:64-101) therefore run on the
+# LSTM device path.  Like every network row, this rests on Chainer 3.5 semantics that cannot be pinned here.
+LSTM_EQUIVALENT = ("lstm", "zoneoutlstm", "zoneoutdropoutlstm")
 ALL_REFERENCE_NETWORKS = ("ff", "tdnn", "lstm", "zoneoutlstm", "zoneoutdropoutlstm", "peepholelstm", "gru", "mgrurelu", "mgrurelur")
 
 
@@ -20,6 +25,8 @@ class NetworkSpec:
     """An un-initialised network, as ``get_nn`` returns it; ``chainer_npz.load_npz`` fills the parameters."""
 
     def __init__(self, network, layers, units, num_classes, activation="relu"):
+        self.reference_network = network                                   # the name given on the command line
+        network = "lstm" if network in LSTM_EQUIVALENT else network        # the device path that runs it
         self.network = network
         self.layers = int(layers)
         self.units = int(units)

@@ -70,6 +70,8 @@ def test_get_nn_scope():
     assert networks.is_nn_recurrent("mgrurelu") and not networks.is_nn_recurrent("ff") and not networks.is_nn_recurrent("tdnn")
     with pytest.raises(NotImplementedError):
         networks.get_nn("gru", 2, [64], 1909)
+    z = networks.get_nn("zoneoutlstm", 2, [64], 1909, "relu", [5], [0.5, 0.5])  # inference-equivalent to lstm
+    assert z.network == "lstm" and z.reference_network == "zoneoutlstm" and z.recurrent
     with pytest.raises(ValueError):
         networks.get_nn("nope", 2, [64], 1909)
     with pytest.raises(ValueError):
