@@ -138,7 +138,8 @@ int am_forward_ff(am_pipeline* p, const float* x, const float* ivec, int64_t n, 
  * timedelay >= 0: output frame j of an utterance is the network output at step j + timedelay
  * (predict_folds.py:59-61).  The reference edge-pads each utterance by `timedelay` rows (predict_folds.py:39) but
  * stores a step only for utterances whose un-padded length exceeds t (predict_folds.py:50,61), so the last
- * `timedelay` output frames of every utterance are exactly 0 -- reproduced here.  Pass 0 for the evaluate
+ * `timedelay` output frames of every utterance are exactly 0 (or -log C after the dev-mode renormalisation of
+ * AM_COMBINE_LOGPOST, predict_folds.py:219) -- reproduced here.  Pass 0 for the evaluate
  * behaviour (evaluateModelForTest.py:67-80).  y: [N, C] in file order. */
 int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec, const int64_t* offsets, int n_utts, int timedelay);
 int am_lstm_run(am_pipeline* p);

@@ -122,6 +122,7 @@ struct am_pipeline {
     std::vector<int> n_active;
     int64_t n_packed = 0;
     int n_slots = 0;
+    int timedelay = 0;
     // the recurrent launch sequence (thousands of ~2 us kernels) is replayed from a hipGraph from the 2nd run on
     int lstm_runs = 0;
     hipGraph_t graph = nullptr;
@@ -801,10 +802,9 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
     AM_TRY(p->d_acc.ensure(sizeof(float) * rows_pad * m0->C_pad));
     if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(p->d_acc2.ensure(sizeof(float) * rows_pad * m0->C_pad));
     AM_TRY(p->d_out.ensure(std::max<size_t>(sizeof(float) * N * m0->C, 16)));
-    if (timedelay > 0 && N > 0) HIP_TRY(hipMemsetAsync(p->d_out.p, 0, sizeof(float) * N * m0->C, e->stream));  // yb = np.zeros(...)
     AM_TRY(sync_all(e));
     p->drop_graph();
-    p->n = N; p->n_packed = NP; p->n_slots = n_utts; p->has_ivec = ivec != nullptr;
+    p->n = N; p->n_packed = NP; p->n_slots = n_utts; p->has_ivec = ivec != nullptr; p->timedelay = timedelay;
     p->mode = 2;
     return AM_OK;
 }
@@ -839,6 +839,16 @@ static int lstm_enqueue(am_pipeline* p)
     am_model* m0 = p->members[0];
     const int64_t NP = p->n_packed, rows_pad = round_up(NP, GEMM_BM);
     const int64_t T = (int64_t)p->n_active.size();
+    if (p->timedelay > 0) {
+        // rows the time loop never stores (the last `timedelay` frames of every utterance, predict_folds.py:50,61) keep
+        // yb's initial zeros; in dev mode those zero rows then go through the final `y - logsum(y)` (predict_folds.py:219),
+        // which turns an all-zero row into -log(C)
+        const bool renorm = p->combine == AM_COMBINE_LOGPOST && p->normalise;
+        const float fill = renorm ? -logf((float)m0->C) : 0.0f;
+        int bits;
+        memcpy(&bits, &fill, sizeof(bits));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p->d_out.p, bits, (size_t)p->n * m0->C, e->stream));
+    }
     GatherArgs ga{};
     ga.x = p->d_x.as<float>(); ga.ivec = p->has_ivec ? p->d_ivec.as<float>() : nullptr; ga.src = p->d_src.as<int>();
     ga.n = NP; ga.n_pad = rows_pad; ga.D = p->D;

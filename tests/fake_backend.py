@@ -110,8 +110,9 @@ class Pipeline:
             return res
 
         y = self._finish(logits, x.shape[0])
-        if timedelay > 0:  # zero tail quirk of predict_folds.py:50,61
-            shifted = np.zeros_like(y)
+        if timedelay > 0:  # zero tail quirk of predict_folds.py:50,61 (dev mode renormalises the zero rows: -log C)
+            fill = -np.log(np.float32(self.num_classes)) if (self.combine == AM_COMBINE_LOGPOST and self.normalise) else 0.0
+            shifted = np.full_like(y, fill)
             for u in range(len(offsets) - 1):
                 lo, hi = offsets[u], offsets[u + 1]
                 if hi - lo > timedelay:

@@ -3,6 +3,8 @@
 The network arithmetic has no reference-held golden vector (Chainer absent: "parity unpinned", see oracle header);
 the oracle here is the self-oracle restating Chainer's CPU semantics, with a float64 shadow for error budgeting.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -201,3 +203,68 @@ def test_api_errors(engine):
         p.forward_ff(np.zeros((10, 40), dtype=np.float32))
     with pytest.raises(ValueError):
         _mk(engine, "gru", 1, {})
+
+
+def test_lstm_ensembles_ivectors_and_dev_average(engine, real_ft_path, real_priors):
+    """Recurrent members through NNWithRPL (evaluate.py:35-51), i-vector columns appended after the transform
+    (evaluate.py:169-171) and the dev-mode log-posterior average (predict_folds.py:199-220) on the recurrent path."""
+    from nnacousticmodeling_amd._lib import AM_COMBINE_LOGPOST
+    rng = np.random.default_rng(71)
+    ft = orc.centre_frame_transform(_ft(real_ft_path))
+    n, d_iv = 260, 12
+    offsets = orc.make_offsets(rng, 7, n, lo=10, hi=80)
+    x = rng.standard_normal((n, 40)).astype(np.float32)
+    iv = rng.standard_normal((n, d_iv)).astype(np.float32)
+    plist = [orc.make_lstm_params(rng, 40 + d_iv, 64, 2, 1909) for _ in range(3)]
+    omodels = [orc.LSTM(q, 2) for q in plist]
+    gmodels = [_mk(engine, "lstm", 2, q) for q in plist]
+    data = orc.evaluate_frontend(x, 0, ft, iv)
+    # master + 2 folds, priors subtracted
+    want = np.concatenate(orc.evaluate_posteriors(orc.NNWithRPL(omodels[0], omodels[1:]), data, offsets, ap=real_priors, rnn=True))
+    p = _pipe(engine)
+    p.set_frontend(40, [0], ft["addShift"], ft["rescale"], d_iv)
+    p.set_members(gmodels, has_master=True)
+    p.set_prior(real_priors)
+    got = p.forward_lstm(x, offsets, ivec=iv)
+    assert np.max(np.abs(got - want)) <= TOL
+    # dev-mode average of per-member log-posteriors (predict semantics, timedelay 2); predict_folds concatenates the
+    # i-vectors BEFORE the (absent) transform, which for ft=None is the same matrix
+    xcat = np.concatenate((x, iv), axis=1)
+    want = orc.fold_average_dev(omodels, xcat, offsets, True, 1, 2, None)
+    p2 = _pipe(engine)
+    p2.set_frontend(40 + d_iv, [0])
+    p2.set_members(gmodels, combine=AM_COMBINE_LOGPOST)
+    got = p2.forward_lstm(xcat, offsets, timedelay=2)
+    assert np.max(np.abs(got - want)) <= TOL
+
+
+def test_chunked_paths_in_a_fresh_process(real_ft_path):
+    """The chunk loops (device-resident chunks and the pipelined host-to-host chunks) only engage above 2^18 / 2^16 rows;
+    shrink them through the environment in a fresh process and compare with the un-chunked result."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd())
+from oracle import am_oracle as orc
+from nnacousticmodeling_amd.engine import Engine, Model, Pipeline
+rng = np.random.default_rng(3)
+ft = orc.load_kaldi_feature_transform(sys.argv[1])
+params = orc.make_mlp_params(rng, 440, 128, 2, 1909)
+x = rng.standard_normal((1500, 40)).astype(np.float32)
+eng = Engine(0)
+p = Pipeline(eng); p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"]); p.set_members([Model(eng, "ff", 2, params)])
+y1 = p.forward_ff(x)                      # pipelined host-to-host chunks (AM_FF_PIPE_ROWS)
+p.ff_upload(x, None, 1500, 0, 0); p.ff_run(); y2 = p.ff_download()   # device-resident chunks (AM_FF_CHUNK_ROWS)
+np.save(sys.argv[2], np.stack([y1, y2]))
+'''
+    import tempfile
+    outs = []
+    for env in ({"AM_FF_CHUNK_ROWS": "512", "AM_FF_PIPE_ROWS": "256"}, {}):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "y.npy")
+            res = subprocess.run([sys.executable, "-c", code, real_ft_path, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300,
+                                 cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            assert res.returncode == 0, res.stderr[-2000:]
+            outs.append(np.load(out))
+    assert np.array_equal(outs[0][0], outs[0][1]) and np.array_equal(outs[0], outs[1])  # chunking never changes a row
