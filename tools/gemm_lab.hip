@@ -136,7 +136,61 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_var(const float* __re
 #pragma unroll
         for (int t = 0; t < TS; ++t) { mma(fav, fbv); asm volatile("" : "+v"(fav[0]), "+v"(fbv[0])); }
     };
-    if (ORDER == 2) {
+    if constexpr (ORDER == 3) {
+        // order 2 (LDS-DMA issue interleaved between MFMA groups) + software pipelining across the barrier: the last
+        // 8-k sub-step of stage kt is multiplied AFTER the barrier that publishes stage kt+1, covering the latency of the
+        // first fragment reads of the new stage.
+        constexpr int SLOTS = (TS - 1) * 4;      // the last sub-step runs after the barrier: no LDS-DMA issue there
+        static_assert(LOADS <= SLOTS, "order 3 needs (TS-1)*4 >= LOADS");
+        constexpr int EVERY = SLOTS / LOADS > 0 ? SLOTS / LOADS : 1;
+        stage(0, 0);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        f32x4 av[2][MI], bv[2][NI];
+        {
+            const f32x4* a4 = (const f32x4*)(smem);
+            const f32x4* w4 = (const f32x4*)(smem + BM * BK * 4);
+            load_frag(a4, w4, 0, av[0], bv[0]);
+        }
+        int cur = 0;   // register set holding the fragments of the NEXT sub-step to multiply
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            const int kn = kt + 1 < nk ? kt + 1 : nk - 1;
+            char* sbase = smem + (buf ^ 1) * STAGE_BYTES;
+            const int k0 = kn * BK;
+            const f32x4* a4 = (const f32x4*)(smem + buf * STAGE_BYTES);
+            const f32x4* w4 = (const f32x4*)(smem + buf * STAGE_BYTES + BM * BK * 4);
+#pragma unroll
+            for (int t = 0; t < TS; ++t) {
+                if (t + 1 < TS) load_frag(a4, w4, t + 1, av[cur ^ 1], bv[cur ^ 1]);
+                else {
+                    // stage kt fully read into registers: publish point for stage kt+1
+                    wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                    const f32x4* na4 = (const f32x4*)(smem + (buf ^ 1) * STAGE_BYTES);
+                    const f32x4* nw4 = (const f32x4*)(smem + (buf ^ 1) * STAGE_BYTES + BM * BK * 4);
+                    load_frag(na4, nw4, 0, av[cur ^ 1], bv[cur ^ 1]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][mi][j], bv[cur][ni][j], acc[mi][ni], 0, 0, 0);
+                    // LDS-DMA of stage kt+1 goes into the other buffer: legal only while that buffer is not being read,
+                    // i.e. during sub-steps 0..TS-2 of this stage (its last readers passed the previous barrier)
+                    const int slot = t * 4 + j;
+                    if (t + 1 < TS && slot % EVERY == 0 && slot / EVERY < LOADS) {
+                        const int l = slot / EVERY;
+                        if (l < A_PER_WAVE) __builtin_amdgcn_global_load_lds(GP(ga[l] + k0), LP(sbase + (l * NW + wave) * 1024), 16, 0, 0);
+                        else __builtin_amdgcn_global_load_lds(GP(gw[l - A_PER_WAVE] + k0), LP(sbase + BM * BK * 4 + ((l - A_PER_WAVE) * NW + wave) * 1024), 16, 0, 0);
+                    }
+                }
+                cur ^= 1;
+            }
+        }
+    } else if constexpr (ORDER == 2) {
         constexpr int P = STAGES - 1;
         constexpr int SLOTS = TS * 4;                    // MFMA groups per k-step
         constexpr int EVERY = SLOTS / LOADS > 0 ? SLOTS / LOADS : 1;
@@ -178,7 +232,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_var(const float* __re
             buf = (buf + 1 == STAGES) ? 0 : buf + 1;
             nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
         }
-    } else if (ORDER == 0) {
+    } else if constexpr (ORDER == 0) {
         stage(0, 0);
         wait_vmcnt<0>();
         __syncthreads();
@@ -256,21 +310,14 @@ int main(int argc, char** argv)
 
     std::vector<Variant> vars;
     if (N % 384 == 0 && N % 256 != 0) vars = {
-        {"v0  128x128x32 s2 2x2 w2 order0 (round-1a)", launch_var<128, 128, 32, 2, 2, 2, 2, 0, 0, 0>},
-        {"v20 256x128x32 s2 4x2 w2 order0 (8 waves)", launch_var<256, 128, 32, 2, 4, 2, 2, 0, 0, 0>},
-        {"v30 256x384x16 s2 4x2 w2 order1 (64x192/wave)", launch_var<256, 384, 16, 2, 4, 2, 2, 1, 0, 0>},
-        {"v31 256x384x32 s2 4x2 w2 order1", launch_var<256, 384, 32, 2, 4, 2, 2, 1, 0, 0>},
+        {"v30 256x384x16 s2 4x2 w2 order1 (product)", launch_var<256, 384, 16, 2, 4, 2, 2, 1, 0, 0>},
         {"v32 256x384x32 s2 4x2 w2 order2", launch_var<256, 384, 32, 2, 4, 2, 2, 2, 0, 0>},
-        {"v33 256x384x16 s3 4x2 w2 order1", launch_var<256, 384, 16, 3, 4, 2, 2, 1, 0, 0>},
-        {"v34 256x384x16 s2 4x2 w2 order0", launch_var<256, 384, 16, 2, 4, 2, 2, 0, 0, 0>},
-        {"v35 128x384x32 s2 2x2 w1 order1 (4 waves 64x192, 2 blk/CU)", launch_var<128, 384, 32, 2, 2, 2, 1, 1, 0, 0>},
+        {"v42 256x384x32 s2 4x2 w2 order3", launch_var<256, 384, 32, 2, 4, 2, 2, 3, 0, 0>},
     };
     else vars = {
-        {"v0  128x128x32 s2 2x2 w2 order0 (round-1a)", launch_var<128, 128, 32, 2, 2, 2, 2, 0, 0, 0>},
-        {"v12 256x256x16 s2 4x2 w2 order1 (8 waves, 64x128/wave)", launch_var<256, 256, 16, 2, 4, 2, 2, 1, 0, 0>},
+        {"v26 256x256x32 s2 4x2 w2 order2 (product)", launch_var<256, 256, 32, 2, 4, 2, 2, 2, 0, 0>},
+        {"v40 256x256x32 s2 4x2 w2 order3 (pipelined across the barrier)", launch_var<256, 256, 32, 2, 4, 2, 2, 3, 0, 0>},
         {"v15 256x256x32 s2 4x2 w2 order0", launch_var<256, 256, 32, 2, 4, 2, 2, 0, 0, 0>},
-        {"v26 256x256x32 s2 4x2 w2 order2", launch_var<256, 256, 32, 2, 4, 2, 2, 2, 0, 0>},
-        {"v36 256x256x32 s2 2x4 w2 order2", launch_var<256, 256, 32, 2, 2, 4, 2, 2, 0, 0>},
     };
     if (M % 256) { printf("M must be a multiple of 256\n"); return 1; }
 
