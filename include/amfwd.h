@@ -57,6 +57,17 @@ int am_engine_destroy(am_engine* e);
 int am_engine_synchronize(am_engine* e);
 int am_engine_device_name(am_engine* e, char* buf, int buflen);
 
+/* Arithmetic of the feed-forward Linear layers.
+ *   AM_PRECISION_F32 (default): exact f32 MFMA (v_mfma_f32_32x32x2_f32), bit-for-bit an fmaf chain.
+ *   AM_PRECISION_SPLIT_F16   : every f32 operand is carried as two f16 halves (x = hi + lo) and each product is formed as
+ *       lo*wh + hi*wl + hi*wh on the f16 matrix pipe with f32 accumulation -- f32-accurate (error against an f64 reference
+ *       not larger than the exact path's), ~2.4x faster.  If an activation does not fit f16 the kernels raise a
+ *       flag: am_forward_ff then repeats the pass on the exact path by itself; callers of am_ff_run check
+ *       am_pipeline_overflowed().  The recurrent path always uses AM_PRECISION_F32. */
+enum { AM_PRECISION_F32 = 0, AM_PRECISION_SPLIT_F16 = 1 };
+int am_engine_set_precision(am_engine* e, int precision);
+int am_pipeline_overflowed(am_pipeline* p, int* flag);   /* synchronises; flag = 1 if the last run overflowed f16 */
+
 /* HIP events on the engine's compute stream (the stream every kernel below is launched on).
  * slot in [0, 64).  Used by bench.py for the timed region. */
 int am_event_record(am_engine* e, int slot);

@@ -15,6 +15,7 @@ AM_OK = 0
 AM_NET_FF, AM_NET_LSTM = 0, 1
 AM_ACT_RELU, AM_ACT_SIGMOID, AM_ACT_TANH = 0, 1, 2
 AM_COMBINE_LOGITS, AM_COMBINE_LOGPOST = 0, 1
+AM_PRECISION_F32, AM_PRECISION_SPLIT_F16 = 0, 1
 AM_KERNEL_ID_MAX = 16
 
 c_float_p = C.POINTER(C.c_float)
@@ -31,6 +32,8 @@ SIGNATURES = {
     "am_engine_destroy": (C.c_int, [C.c_void_p]),
     "am_engine_synchronize": (C.c_int, [C.c_void_p]),
     "am_engine_device_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "am_engine_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "am_pipeline_overflowed": (C.c_int, [C.c_void_p, c_int_p]),
     "am_event_record": (C.c_int, [C.c_void_p, C.c_int]),
     "am_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p]),
     "am_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

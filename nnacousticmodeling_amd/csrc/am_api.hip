@@ -71,6 +71,8 @@ struct am_engine {
     hipStream_t stream2 = nullptr;   // copy stream: D2H of chunk c overlaps the compute of chunk c+1 (am_forward_ff)
     hipEvent_t s2_tail = nullptr;    // last work enqueued on stream2
     bool s2_dirty = false;
+    int precision = AM_PRECISION_F32;  // AM_PRECISION_* for the feed-forward Linear layers
+    DevBuf d_overflow;                 // int flag raised by split-f16 kernels when an activation does not fit f16
     hipEvent_t ev[64] = {};
     bool profile = false;
     struct Rec { int id; hipEvent_t a, b; };
@@ -86,6 +88,11 @@ struct Layer {
     int in = 0, out = 0, in_pad = 0, out_pad = 0;
     int U = 0, U_pad = 0;  // LSTM layers only
     DevBuf W, b, Wlat;
+    // split-f16 precision mode (feed-forward only), built on first use
+    float wmax = 0.f;      // max |W| (host scan at creation)
+    float w_scale = 1.f;   // exact power of two applied to W before splitting
+    int out_pad_s = 0;     // output width padded to 256
+    DevBuf Whi, Wlo, b_s;
 };
 
 struct am_model {
@@ -94,6 +101,7 @@ struct am_model {
     std::vector<Layer> L;  // n_layers + 1 (last = output Linear)
     int in_dim = 0, in_pad = 0, C = 0, C_pad = 0;
     int max_width = 0;     // widest padded hidden activation
+    int split_state = 0;   // 0 not built, 1 ready, -1 unsupported shape (falls back to the exact path)
 };
 
 struct am_pipeline {
@@ -114,7 +122,9 @@ struct am_pipeline {
     int64_t n = 0;
     int halo_lo = 0, halo_hi = 0;
     bool has_ivec = false;
-    DevBuf d_x, d_ivec, d_in, d_act0, d_act1, d_acc, d_acc2, d_out;
+    DevBuf d_x, d_ivec, d_in, d_in_s, d_act0, d_act1, d_acc, d_acc2, d_out;
+    int acc_ld = 0;        // leading dimension of d_acc / d_acc2 in the current run (C_pad, or C padded to 256 in split mode)
+    bool ran_split = false;
     std::vector<hipEvent_t> chunk_done;  // one-shot path: chunk c's posteriors are final (compute stream -> copy stream)
     // lstm
     DevBuf d_src, d_dst, d_G, d_H, d_c;   // d_H / d_c: one packed H plane and one cell-state array per layer
@@ -216,7 +226,7 @@ extern "C" const char* am_version(void) { return "amfwd 0.1 (gfx950)"; }
 
 extern "C" const char* am_kernel_name(int id)
 {
-    static const char* names[K_COUNT] = {"splice_ft", "gemm_hidden", "gemm_out", "finish", "gather_ft", "lstm_upward", "lstm_step", "viterbi"};
+    static const char* names[K_COUNT] = {"splice_ft", "gemm_hidden", "gemm_out", "finish", "gather_ft", "lstm_upward", "lstm_step", "viterbi", "split_convert", "gemm_split"};
     return (id >= 0 && id < K_COUNT) ? names[id] : nullptr;
 }
 
@@ -256,6 +266,7 @@ extern "C" int am_engine_destroy(am_engine* e)
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& s : e->scratch) s.release();
+    e->d_overflow.release();
     (void)hipStreamDestroy(e->stream);
     delete e;
     return AM_OK;
@@ -291,6 +302,26 @@ extern "C" int am_event_elapsed_ms(am_engine* e, int a, int b, float* ms)
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipEventSynchronize(e->ev[b]));
     HIP_TRY(hipEventElapsedTime(ms, e->ev[a], e->ev[b]));
+    return AM_OK;
+}
+
+extern "C" int am_engine_set_precision(am_engine* e, int precision)
+{
+    if (!e || (precision != AM_PRECISION_F32 && precision != AM_PRECISION_SPLIT_F16)) return fail(AM_EINVAL, "am_engine_set_precision: bad argument");
+    e->precision = precision;
+    return AM_OK;
+}
+
+extern "C" int am_pipeline_overflowed(am_pipeline* p, int* flag)
+{
+    if (!p || !flag) return fail(AM_EINVAL, "am_pipeline_overflowed: bad argument");
+    *flag = 0;
+    if (!p->ran_split) return AM_OK;
+    am_engine* e = p->e;
+    HIP_TRY(hipSetDevice(e->device));
+    AM_TRY(join_streams(e));
+    HIP_TRY(hipMemcpyAsync(flag, e->d_overflow.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return AM_OK;
 }
 
@@ -409,6 +440,8 @@ extern "C" int am_model_create(am_engine* e, int kind, int n_layers, int activat
             m->max_width = std::max(m->max_width, Ly.U_pad);
         } else {
             Ly.out_pad = gemm_n_pad(Ly.out);
+            Ly.out_pad_s = (int)round_up(Ly.out, 256);
+            for (size_t i = 0; i < (size_t)Ly.out * Ly.in; ++i) Ly.wmax = std::max(Ly.wmax, fabsf(W[l][i]));
             std::vector<float> w((size_t)Ly.out_pad * Ly.in_pad, 0.f), bb(Ly.out_pad, 0.f);
             for (int o = 0; o < Ly.out; ++o) memcpy(&w[(size_t)o * Ly.in_pad], W[l] + (size_t)o * Ly.in, sizeof(float) * Ly.in);
             memcpy(bb.data(), b[l], sizeof(float) * Ly.out);
@@ -426,7 +459,7 @@ extern "C" int am_model_destroy(am_model* m)
 {
     if (!m) return AM_OK;
     (void)hipSetDevice(m->e->device);
-    for (auto& l : m->L) { l.W.release(); l.b.release(); l.Wlat.release(); }
+    for (auto& l : m->L) { l.W.release(); l.b.release(); l.Wlat.release(); l.Whi.release(); l.Wlo.release(); l.b_s.release(); }
     delete m;
     return AM_OK;
 }
@@ -451,7 +484,7 @@ extern "C" int am_pipeline_destroy(am_pipeline* p)
     (void)hipStreamSynchronize(p->e->stream2);
     for (auto ev : p->chunk_done) (void)hipEventDestroy(ev);
     p->drop_graph();
-    for (DevBuf* d : {&p->d_shifts, &p->d_add, &p->d_scale, &p->d_rplw, &p->d_rplb, &p->d_rpllb, &p->d_prior, &p->d_x, &p->d_ivec, &p->d_in,
+    for (DevBuf* d : {&p->d_shifts, &p->d_add, &p->d_scale, &p->d_rplw, &p->d_rplb, &p->d_rpllb, &p->d_prior, &p->d_x, &p->d_ivec, &p->d_in, &p->d_in_s,
                       &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c})
         d->release();
     delete p;
@@ -576,8 +609,8 @@ static int member_finish(am_pipeline* p, int mi, int64_t rows)
     // log-posterior averaging: normalise this member and add it to the running sum (predict_folds.py:207-212)
     am_model* m0 = p->members[0];
     FinishArgs f{};
-    f.in = p->d_acc.as<float>(); f.ldin = m0->C_pad;
-    f.out = p->d_acc2.as<float>(); f.ldout = m0->C_pad;
+    f.in = p->d_acc.as<float>(); f.ldin = p->acc_ld;
+    f.out = p->d_acc2.as<float>(); f.ldout = p->acc_ld;
     f.n = rows; f.C = m0->C; f.normalise = 1; f.accumulate = mi > 0;
     return run_kernel(p->e, K_FINISH, [&] { return launch_finish(p->e->stream, f); });
 }
@@ -586,7 +619,7 @@ static int final_finish(am_pipeline* p, int64_t rows, float* out, const int* row
 {
     am_model* m0 = p->members[0];
     FinishArgs f{};
-    f.in = (p->combine == AM_COMBINE_LOGPOST ? p->d_acc2 : p->d_acc).as<float>(); f.ldin = m0->C_pad;
+    f.in = (p->combine == AM_COMBINE_LOGPOST ? p->d_acc2 : p->d_acc).as<float>(); f.ldin = p->acc_ld;
     f.out = out; f.ldout = m0->C; f.row_map = row_map;
     f.n = rows; f.C = m0->C;
     f.divisor = final_divisor(p);
@@ -624,8 +657,10 @@ extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, i
         AM_TRY(p->d_act0.ensure(sizeof(float) * rows * width));
         AM_TRY(p->d_act1.ensure(sizeof(float) * rows * width));
     }
-    AM_TRY(p->d_acc.ensure(sizeof(float) * rows * m0->C_pad));
-    if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(p->d_acc2.ensure(sizeof(float) * rows * m0->C_pad));
+    const int acc_w = std::max<int>(m0->C_pad, (int)round_up(m0->C, 256));
+    AM_TRY(p->d_acc.ensure(sizeof(float) * rows * acc_w));
+    if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(p->d_acc2.ensure(sizeof(float) * rows * acc_w));
+    AM_TRY(p->d_in_s.ensure(sizeof(float) * rows * m0->in_pad));
     AM_TRY(p->d_out.ensure(std::max<size_t>(sizeof(float) * n * m0->C, 16)));
     AM_TRY(sync_all(e));
     p->n = n; p->halo_lo = halo_lo; p->halo_hi = halo_hi; p->has_ivec = ivec != nullptr;
@@ -658,6 +693,69 @@ static int ff_member_forward(am_pipeline* p, int mi, int64_t rows_pad, float* ac
     return AM_OK;
 }
 
+// ---- split-f16 precision mode ---------------------------------------------------------------------
+// Builds, once per model, the hi/lo half copies of the (zero-padded) weights, pre-scaled by an exact power of two so that
+// max |W'| lies in [512, 1024] and the lo halves are normal f16 numbers.  Hidden widths must already be multiples of 256
+// (the exact path may have padded to 384); otherwise the model stays on the exact path.
+static int ensure_split_weights(am_model* m)
+{
+    if (m->split_state != 0) return AM_OK;
+    am_engine* e = m->e;
+    for (int l = 0; l < m->n_layers; ++l)
+        if (m->L[l].out_pad % 256) { m->split_state = -1; return AM_OK; }
+    for (int l = 0; l <= m->n_layers; ++l) {
+        Layer& Ly = m->L[l];
+        const float wmax = Ly.wmax > 0.f ? Ly.wmax : 1.f;
+        Ly.w_scale = exp2f(floorf(log2f(1024.0f / wmax)));
+        const size_t rows_s = (size_t)Ly.out_pad_s, halves = rows_s * Ly.in_pad;
+        AM_TRY(Ly.Whi.ensure(halves * 2));
+        AM_TRY(Ly.Wlo.ensure(halves * 2));
+        AM_TRY(Ly.b_s.ensure(sizeof(float) * rows_s));
+        HIP_TRY(hipMemsetAsync(Ly.Whi.p, 0, halves * 2, e->stream));
+        HIP_TRY(hipMemsetAsync(Ly.Wlo.p, 0, halves * 2, e->stream));
+        HIP_TRY(hipMemsetAsync(Ly.b_s.p, 0, sizeof(float) * rows_s, e->stream));
+        const size_t rows_have = (size_t)std::min(Ly.out_pad, Ly.out_pad_s);   // rows beyond `out` are zero in W already
+        HIP_TRY(hipMemcpyAsync(Ly.b_s.p, Ly.b.p, sizeof(float) * rows_have, hipMemcpyDeviceToDevice, e->stream));
+        AM_TRY(run_kernel(e, K_SPLIT_CONVERT, [&] { return launch_split_f32(e->stream, Ly.W.as<float>(), Ly.Whi.p, Ly.Wlo.p, rows_have * Ly.in_pad, Ly.w_scale, nullptr); }));
+    }
+    m->split_state = 1;
+    return AM_OK;
+}
+
+static bool use_split(am_pipeline* p)
+{
+    if (p->e->precision != AM_PRECISION_SPLIT_F16) return false;
+    for (auto* m : p->members) if (m->split_state != 1) return false;
+    return true;
+}
+
+static int ff_member_forward_split(am_pipeline* p, int mi, int64_t rows_pad, float* acc)
+{
+    am_engine* e = p->e;
+    am_model* m = p->members[mi];
+    int* flag = e->d_overflow.as<int>();
+    // activations travel as two half matrices inside one f32-sized buffer: hi at the base, lo right behind it
+    const _Float16* Ahi = (const _Float16*)p->d_in_s.p;
+    const _Float16* Alo = Ahi + (size_t)rows_pad * m->in_pad;
+    int lda = m->in_pad;
+    for (int l = 0; l <= m->n_layers; ++l) {
+        Layer& Ly = m->L[l];
+        SplitGemmArgs g{};
+        g.Ahi = Ahi; g.Alo = Alo; g.lda = lda; g.Whi = Ly.Whi.p; g.Wlo = Ly.Wlo.p; g.ldw = Ly.in_pad; g.bias = Ly.b_s.as<float>();
+        g.M_pad = (int)rows_pad; g.N_pad = Ly.out_pad_s; g.K_pad = Ly.in_pad; g.act = m->act; g.out_scale = 1.0f / Ly.w_scale; g.overflow = flag;
+        if (l < m->n_layers) {
+            _Float16* Chi = (_Float16*)((l & 1) ? p->d_act1 : p->d_act0).p;
+            g.C = nullptr; g.Chi = Chi; g.Clo = Chi + (size_t)rows_pad * Ly.out_pad_s; g.ldc = Ly.out_pad_s; g.epi = EPI_ACT; g.alpha = 1.f;
+            AM_TRY(run_kernel(e, K_GEMM_SPLIT, [&] { return launch_gemm_split(e->stream, g); }));
+            Ahi = (const _Float16*)g.Chi; Alo = (const _Float16*)g.Clo; lda = g.ldc;
+        } else {
+            g.C = acc; g.ldc = p->acc_ld; g.epi = epilogue_mode(p, mi, &g.alpha);
+            AM_TRY(run_kernel(e, K_GEMM_SPLIT, [&] { return launch_gemm_split(e->stream, g); }));
+        }
+    }
+    return AM_OK;
+}
+
 // One pass over the resident shard in chunks of `chunk_rows`.  With `host_y` the posteriors of chunk c are copied back on
 // the copy stream while the compute stream works on chunk c+1 (all compute is enqueued first, then the copies, so the
 // overlap also holds for pageable host memory, where hipMemcpyAsync blocks the calling thread).
@@ -666,6 +764,15 @@ static int ff_run_chunks(am_pipeline* p, int64_t chunk_rows, float* host_y)
     am_engine* e = p->e;
     am_model* m0 = p->members[0];
     size_t n_chunks = 0;
+    if (e->precision == AM_PRECISION_SPLIT_F16)
+        for (auto* m : p->members) AM_TRY(ensure_split_weights(m));
+    const bool split = use_split(p);
+    p->ran_split = split;
+    p->acc_ld = split ? (int)round_up(m0->C, 256) : m0->C_pad;
+    if (split) {
+        AM_TRY(e->d_overflow.ensure(16));
+        HIP_TRY(hipMemsetAsync(e->d_overflow.p, 0, sizeof(int), e->stream));
+    }
     for (int64_t c0 = 0; c0 < p->n; c0 += chunk_rows, ++n_chunks) {
         const int64_t nc = std::min<int64_t>(chunk_rows, p->n - c0);
         const int64_t nc_pad = round_up(nc, GEMM_BM);
@@ -676,8 +783,14 @@ static int ff_run_chunks(am_pipeline* p, int64_t chunk_rows, float* host_y)
         s.add = p->has_ft ? p->d_add.as<float>() : nullptr; s.scale = p->has_ft ? p->d_scale.as<float>() : nullptr;
         s.d_iv = p->d_iv; s.out = p->d_in.as<float>(); s.ldo = m0->in_pad;
         AM_TRY(run_kernel(e, K_SPLICE_FT, [&] { return launch_splice_ft(e->stream, s); }));
+        if (split) {   // frontend output -> hi/lo halves, shared by every member
+            _Float16* hi = (_Float16*)p->d_in_s.p;
+            AM_TRY(run_kernel(e, K_SPLIT_CONVERT, [&] { return launch_split_f32(e->stream, p->d_in.as<float>(), hi, hi + (size_t)nc_pad * m0->in_pad,
+                                                                                 (size_t)nc_pad * m0->in_pad, 1.0f, e->d_overflow.as<int>()); }));
+        }
         for (int mi = 0; mi < (int)p->members.size(); ++mi) {
-            AM_TRY(ff_member_forward(p, mi, nc_pad, p->d_acc.as<float>()));
+            if (split) AM_TRY(ff_member_forward_split(p, mi, nc_pad, p->d_acc.as<float>()));
+            else AM_TRY(ff_member_forward(p, mi, nc_pad, p->d_acc.as<float>()));
             if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(member_finish(p, mi, nc));
         }
         AM_TRY(final_finish(p, nc, p->d_out.as<float>() + c0 * m0->C, nullptr));
@@ -726,7 +839,18 @@ extern "C" int am_forward_ff(am_pipeline* p, const float* x, const float* ivec, 
     AM_TRY(am_ff_upload(p, x, ivec, n, halo_lo, halo_hi));
     if (!y) return fail(AM_EINVAL, "am_forward_ff: y is NULL");
     AM_TRY(ff_run_chunks(p, FF_PIPE_ROWS, y));   // download of chunk c overlaps the compute of chunk c+1
-    return sync_all(p->e);
+    AM_TRY(sync_all(p->e));
+    int over = 0;
+    AM_TRY(am_pipeline_overflowed(p, &over));
+    if (over) {   // an activation did not fit f16: repeat the pass on the exact f32 path
+        const int keep = p->e->precision;
+        p->e->precision = AM_PRECISION_F32;
+        const int rc = ff_run_chunks(p, FF_PIPE_ROWS, y);
+        p->e->precision = keep;
+        AM_TRY(rc);
+        AM_TRY(sync_all(p->e));
+    }
+    return AM_OK;
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -839,6 +963,7 @@ static int lstm_enqueue(am_pipeline* p)
     am_model* m0 = p->members[0];
     const int64_t NP = p->n_packed, rows_pad = round_up(NP, GEMM_BM);
     const int64_t T = (int64_t)p->n_active.size();
+    p->acc_ld = m0->C_pad;
     if (p->timedelay > 0) {
         // rows the time loop never stores (the last `timedelay` frames of every utterance, predict_folds.py:50,61) keep
         // yb's initial zeros; in dev mode those zero rows then go through the final `y - logsum(y)` (predict_folds.py:219),

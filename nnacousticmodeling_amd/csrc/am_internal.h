@@ -15,7 +15,9 @@ enum KernelId {
     K_LSTM_UPWARD = 5, // hoisted upward GEMM of an LSTM layer (MFMA f32)
     K_LSTM_STEP = 6,   // one wavefront step of the LSTM stack
     K_VITERBI = 7,     // triphone Viterbi decode, one workgroup per utterance
-    K_COUNT = 8
+    K_SPLIT_CONVERT = 8, // f32 -> hi/lo halves (split-f16 mode)
+    K_GEMM_SPLIT = 9,  // Linear layers on the f16 pipe with hi/lo operands (split-f16 mode)
+    K_COUNT = 10
 };
 
 constexpr int GEMM_BM = 256;  // rows per block tile: every activation matrix is padded to a multiple of this
@@ -40,6 +42,20 @@ struct GemmArgs {
 };
 hipError_t init_kernels();  // once per device after hipSetDevice
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
+
+// split-f16 precision mode (see gemm_nt_split_kernel): operands are hi/lo half matrices
+struct SplitGemmArgs {
+    const void* Ahi; const void* Alo; int lda;      // [M_pad, lda] halves
+    const void* Whi; const void* Wlo; int ldw;      // [N_pad, ldw] halves, pre-scaled by 1/out_scale
+    const float* bias;                              // [N_pad]
+    float* C;                                       // output layer: f32 [M_pad, ldc]; nullptr for hidden layers
+    void* Chi; void* Clo; int ldc;                  // hidden layers: act(...) as hi/lo halves [M_pad, ldc]
+    int M_pad, N_pad, K_pad;                        // multiples of GEMM_BM / 256 / 32
+    int act; int epi; float alpha; float out_scale;
+    int* overflow;                                  // device flag, set when an activation does not fit f16
+};
+hipError_t launch_gemm_split(hipStream_t s, const SplitGemmArgs& g);
+hipError_t launch_split_f32(hipStream_t s, const float* x, void* hi, void* lo, size_t n, float scale, int* overflow);
 
 struct SpliceArgs {
     const float* x; int64_t ext_rows; int64_t first;  // x: [ext_rows, D]; output row r reads x[first + r + shift]

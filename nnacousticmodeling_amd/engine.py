@@ -90,6 +90,11 @@ class Engine:
         check(self._lib.am_event_elapsed_ms(self._h, int(a), int(b), C.byref(ms)))
         return float(ms.value)
 
+    def set_precision(self, mode):
+        """"f32" (exact f32 MFMA, default) or "split_f16" (f32-accurate products on the f16 pipe, see include/amfwd.h)."""
+        modes = {"f32": _lib.AM_PRECISION_F32, "exact": _lib.AM_PRECISION_F32, "split_f16": _lib.AM_PRECISION_SPLIT_F16}
+        check(self._lib.am_engine_set_precision(self._h, modes[mode]))
+
     def profile(self, on=True):
         check(self._lib.am_profile_enable(self._h, 1 if on else 0))
 
@@ -292,6 +297,12 @@ class Pipeline:
         check(self._lib.am_forward_ff(self._h, _fp(x_ext), _fp(iv), int(n), int(halo_lo), int(halo_hi), _fp(y)))
         self._n = int(n)
         return y
+
+    def overflowed(self):
+        """True if the last split-f16 run met an activation that does not fit f16 (its results must be recomputed)."""
+        flag = C.c_int(0)
+        check(self._lib.am_pipeline_overflowed(self._h, C.byref(flag)))
+        return bool(flag.value)
 
     # recurrent -------------------------------------------------------------------------------------
     def lstm_upload(self, x, ivec, offsets, timedelay=0):

@@ -268,3 +268,64 @@ np.save(sys.argv[2], np.stack([y1, y2]))
             assert res.returncode == 0, res.stderr[-2000:]
             outs.append(np.load(out))
     assert np.array_equal(outs[0][0], outs[0][1]) and np.array_equal(outs[0], outs[1])  # chunking never changes a row
+
+
+def test_split_f16_precision_mode(engine, real_ft_path, real_priors):
+    """AM_PRECISION_SPLIT_F16: f32 operands as hi+lo f16 halves on the f16 matrix pipe.  Must meet the same 1e-4 bound
+    and be no worse against the float64 shadow than the exact f32 path (x2 slack); ensembles use the same epilogues."""
+    rng = np.random.default_rng(81)
+    ft = _ft(real_ft_path)
+    n = 1200
+    x = rng.standard_normal((n, 40)).astype(np.float32)
+    params = orc.make_mlp_params(rng, 440, 1024, 4, 1909)
+    want = orc.predict(orc.MLP(params, 4), x, None, False, 11, 0, ft)
+    want64 = orc.predict(orc.MLP(params, 4, dtype=np.float64), x, None, False, 11, 0, ft)
+    p = _pipe(engine)
+    p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+    p.set_members([_mk(engine, "ff", 4, params)])
+    exact = p.forward_ff(x)
+    try:
+        engine.set_precision("split_f16")
+        got = p.forward_ff(x)
+        assert not p.overflowed()
+        assert np.max(np.abs(got - want)) <= TOL
+        e_split, e_exact = np.max(np.abs(got - want64)), np.max(np.abs(exact - want64))
+        assert e_split <= max(2 * e_exact, 2e-5), (e_split, e_exact)
+        # shards with halo still reproduce the whole file bit for bit in this mode
+        a = p.forward_ff(x[:605], None, 600, 0, 5)
+        b = p.forward_ff(x[595:], None, n - 600, 5, 0)
+        assert np.array_equal(np.concatenate([a, b]), got)
+        # ensemble + priors + RPL-free logit averaging through the f32 output epilogues
+        plist = [orc.make_mlp_params(rng, 440, 256, 2, 1909) for _ in range(3)]
+        data = orc.evaluate_frontend(x, 5, ft)
+        want_e = np.concatenate(orc.evaluate_posteriors(orc.NNWithRPL(orc.MLP(plist[0], 2), [orc.MLP(q, 2) for q in plist[1:]]), data, np.array([0, n]), ap=real_priors))
+        pe = _pipe(engine)
+        pe.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+        pe.set_members([_mk(engine, "ff", 2, q) for q in plist], has_master=True)
+        pe.set_prior(real_priors)
+        assert np.max(np.abs(pe.forward_ff(x) - want_e)) <= TOL
+        # an activation that cannot be carried in f16 raises the flag; the one-shot call falls back to the exact path
+        big = {k: v.copy() for k, v in params.items()}
+        big["layer_0/W"] *= 1e5       # first hidden layer ~1e5: beyond the f16 range ...
+        big["layer_0/b"] *= 1e5
+        big["layer_1/W"] *= 1e-5      # ... brought back by the next layer, so the final posteriors are ordinary
+        pb = _pipe(engine)
+        pb.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+        pb.set_members([_mk(engine, "ff", 4, big)])
+        pb.ff_upload(x, None, n, 0, 0)
+        pb.ff_run()
+        assert pb.overflowed()
+        want_b = orc.predict(orc.MLP(big, 4), x, None, False, 11, 0, ft)
+        got_b = pb.forward_ff(x)   # automatic exact re-run
+        assert np.all(np.isfinite(got_b)) and np.max(np.abs(got_b - want_b)) <= TOL
+        engine.set_precision("f32")
+        assert np.array_equal(pb.forward_ff(x), got_b)
+        # a hidden width that the exact path pads to 384 is not eligible: the mode silently stays exact
+        p384 = orc.make_mlp_params(rng, 440, 384, 1, 1909)
+        engine.set_precision("split_f16")
+        pq = _pipe(engine)
+        pq.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+        pq.set_members([_mk(engine, "ff", 1, p384)])
+        assert np.max(np.abs(pq.forward_ff(x) - orc.predict(orc.MLP(p384, 1), x, None, False, 11, 0, ft))) <= TOL
+    finally:
+        engine.set_precision("f32")
