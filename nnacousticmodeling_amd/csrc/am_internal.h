@@ -64,6 +64,7 @@ struct SpliceArgs {
     int D; int n_shifts; const int* shifts;           // device pointer
     const float* add; const float* scale;             // device [n_shifts*D] or nullptr
     int d_iv; float* out; int ldo;
+    void* out_hi; void* out_lo; int* overflow;        // split-f16 mode: write hi/lo halves instead of `out`
 };
 hipError_t launch_splice_ft(hipStream_t s, const SpliceArgs& a);
 

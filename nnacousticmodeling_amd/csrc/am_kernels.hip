@@ -13,6 +13,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define AM_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define AM_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+constexpr float SPLIT_F16_LIMIT = 60000.0f;   // |value| above this cannot be carried as an f16 hi half (split-f16 mode)
+
 __device__ __forceinline__ float am_sigmoid(float x) { return tanhf(x * 0.5f) * 0.5f + 0.5f; }
 
 __device__ __forceinline__ float am_activate(float v, int act) {
@@ -235,7 +237,6 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g)
 // 2 LDS stages (128 KiB), LDS-DMA issue interleaved between MFMA groups.
 // ---------------------------------------------------------------------------------------------------
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-constexpr float SPLIT_F16_LIMIT = 60000.0f;   // |activation| above this cannot be carried as an f16 hi half
 
 __global__ __launch_bounds__(256) void split_f32_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
                                                         size_t n, float scale, int* __restrict__ overflow)
@@ -416,12 +417,14 @@ hipError_t launch_gemm_split(hipStream_t s, const SplitGemmArgs& g)
 // out[r, n_shifts*D + j] = ivec[row0 + r, j];  remaining columns up to ldo and rows [n, n_pad) are zero.
 // VEC = 4 needs D % 4 == 0 and d_iv % 4 == 0 (then no float4 straddles a segment); VEC = 1 is the general form.
 // ---------------------------------------------------------------------------------------------------
-template <int VEC>
+// HALVES: write the result as hi/lo f16 halves (split-f16 precision mode: hi at out_hi, lo at out_lo, same [n_pad, ldo] shape)
+// instead of f32, raising *overflow when a value does not fit f16.
+template <int VEC, bool HALVES>
 __global__ __launch_bounds__(256) void splice_ft_kernel(
     const float* __restrict__ x, long long ext_rows, long long first, const float* __restrict__ ivec, long long row0,
     long long n, long long n_pad, int D, int n_shifts, const int* __restrict__ shifts,
     const float* __restrict__ add, const float* __restrict__ scale, int d_iv, float* __restrict__ out, int ldo,
-    int rows_per_block)
+    int rows_per_block, _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo, int* __restrict__ overflow)
 {
     const int Q = ldo / VEC;                 // vector columns per row
     const int Qt = Q < 256 ? Q : 256;        // threads form a [rows_per_pass][Qt] grid; surplus threads idle
@@ -467,9 +470,26 @@ __global__ __launch_bounds__(256) void splice_ft_kernel(
                     else v[0] = p[0];
                 }
             }
-            float* o = out + r * ldo + col;
-            if (VEC == 4) { f32x4 t; t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3]; *(f32x4*)o = t; }
-            else o[0] = v[0];
+            if (HALVES) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                _Float16 hh[VEC], ll[VEC];
+                bool bad = false;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    hh[e] = (_Float16)v[e];
+                    ll[e] = (_Float16)(v[e] - (float)hh[e]);
+                    bad |= !(fabsf(v[e]) <= SPLIT_F16_LIMIT);
+                }
+                if (VEC == 4) {
+                    *(h4*)(out_hi + r * ldo + col) = (h4){hh[0], hh[1], hh[2], hh[3]};
+                    *(h4*)(out_lo + r * ldo + col) = (h4){ll[0], ll[1], ll[2], ll[3]};
+                } else { out_hi[r * ldo + col] = hh[0]; out_lo[r * ldo + col] = ll[0]; }
+                if (bad) *overflow = 1;
+            } else {
+                float* o = out + r * ldo + col;
+                if (VEC == 4) { f32x4 t; t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3]; *(f32x4*)o = t; }
+                else o[0] = v[0];
+            }
         }
     }
 }
@@ -480,12 +500,12 @@ hipError_t launch_splice_ft(hipStream_t s, const SpliceArgs& a)
     const bool vec = (a.D % 4 == 0) && (a.d_iv % 4 == 0) && (a.ldo % 4 == 0);
     const int rows_per_block = 32;
     const long long blocks = (a.n_pad + rows_per_block - 1) / rows_per_block;
-    if (vec)
-        hipLaunchKernelGGL(splice_ft_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, a.x, (long long)a.ext_rows, (long long)a.first,
-                           a.ivec, (long long)a.row0, (long long)a.n, (long long)a.n_pad, a.D, a.n_shifts, a.shifts, a.add, a.scale, a.d_iv, a.out, a.ldo, rows_per_block);
-    else
-        hipLaunchKernelGGL(splice_ft_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, a.x, (long long)a.ext_rows, (long long)a.first,
-                           a.ivec, (long long)a.row0, (long long)a.n, (long long)a.n_pad, a.D, a.n_shifts, a.shifts, a.add, a.scale, a.d_iv, a.out, a.ldo, rows_per_block);
+#define AM_SPLICE(V, H) hipLaunchKernelGGL((splice_ft_kernel<V, H>), dim3((unsigned)blocks), dim3(256), 0, s, a.x, (long long)a.ext_rows, (long long)a.first, \
+        a.ivec, (long long)a.row0, (long long)a.n, (long long)a.n_pad, a.D, a.n_shifts, a.shifts, a.add, a.scale, a.d_iv, a.out, a.ldo, rows_per_block, \
+        (_Float16*)a.out_hi, (_Float16*)a.out_lo, a.overflow)
+    if (a.out_hi) { if (vec) AM_SPLICE(4, true); else AM_SPLICE(1, true); }
+    else { if (vec) AM_SPLICE(4, false); else AM_SPLICE(1, false); }
+#undef AM_SPLICE
     return hipGetLastError();
 }
 
