@@ -19,7 +19,7 @@ from . import chainer_npz
 from .evaluate_model_for_test import evaluateModelTestTri
 from .kaldi_ft import loadKaldiFeatureTransform, select_centre_frame
 from .networks import NNWithRPL, RPL4Spec, get_nn, is_nn_recurrent  # noqa: F401  (NNWithRPL re-exported like the reference module)
-from .sharding import parse_devices
+from .sharding import parse_devices, set_default_precision
 
 
 def build_parser():
@@ -60,6 +60,8 @@ def build_parser():
     parser.add_argument("--decoder", default="auto", choices=["auto", "gpu", "subprocess", "none"],
                         help="auto/gpu: in-process GPU Viterbi when <recog-dir>/kaldiTri1909.img exists; subprocess: the reference's PhoneRecog executable")
     parser.add_argument("--no-lab", action="store_true", help="do not write the .lab/.scp posterior files (only the external executable needs them)")
+    parser.add_argument("--precision", default="f32", choices=["f32", "split_f16"],
+                        help="f32: exact f32 MFMA (default); split_f16: f32-accurate Linear layers on the f16 matrix pipe, ~2.3x faster (extension)")
     parser.add_argument("--no-progress", action="store_true", help="Disable progress bar")
     return parser
 
@@ -99,6 +101,7 @@ def main(arg_list=None):
         print("Wrong activation function specified")
         return None
     devices = parse_devices(args.gpu, args.gpus)
+    set_default_precision(args.precision)
     model = load_models(args, num_classes)
     recurrent = is_nn_recurrent(args.network)
 

@@ -74,10 +74,11 @@ class PosteriorRunner:
     ``devices``: list of device ids.  ``backend``: module providing Engine/Model/Pipeline (default: the HIP engine;
     the CPU-only test-suite injects a stand-in to exercise this host logic without a GPU)."""
 
-    def __init__(self, devices=(0,), backend=None):
+    def __init__(self, devices=(0,), backend=None, precision="f32"):
         if backend is None:
             from . import engine as backend
         self.backend = backend
+        self.precision = precision   # "f32" (exact f32 MFMA) or "split_f16" (f32-accurate on the f16 pipe, feed-forward only)
         self.devices = [int(d) for d in devices]
         if not self.devices:
             raise ValueError("no device given")
@@ -92,6 +93,8 @@ class PosteriorRunner:
             st = self._state.get(device)
             if st is None:
                 st = self._state[device] = _DeviceState(self.backend, device)
+                if self.precision != "f32":
+                    st.engine.set_precision(self.precision)
             return st
 
     def _configure(self, st, ensemble, D, shifts, ft, d_iv, prior, combine, normalise):
@@ -202,12 +205,23 @@ class PosteriorRunner:
 _default_runners = {}
 
 
+_default_precision = "f32"
+
+
+def set_default_precision(mode):
+    """Precision of runners created by get_runner() from now on (the CLIs' --precision flag)."""
+    global _default_precision
+    if mode not in ("f32", "split_f16"):
+        raise ValueError("precision must be 'f32' or 'split_f16'")
+    _default_precision = mode
+
+
 def get_runner(devices):
-    """Process-wide cache of runners keyed by the device tuple (models stay resident across calls)."""
-    key = tuple(int(d) for d in devices)
+    """Process-wide cache of runners keyed by the device tuple and precision (models stay resident across calls)."""
+    key = tuple(int(d) for d in devices) + (_default_precision,)
     r = _default_runners.get(key)
     if r is None:
-        r = _default_runners[key] = PosteriorRunner(key)
+        r = _default_runners[key] = PosteriorRunner(key[:-1], precision=_default_precision)
     return r
 
 

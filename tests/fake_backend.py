@@ -20,6 +20,9 @@ class Engine:
     def close(self):
         pass
 
+    def set_precision(self, mode):   # the stand-in computes in numpy f32 either way
+        self.precision = mode
+
 
 class Model:
     def __init__(self, engine, network, layers, params, activation="relu"):
