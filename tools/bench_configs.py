@@ -47,19 +47,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--which", default="all")
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--precision", default="f32", choices=["f32", "split_f16"])
     args = ap.parse_args()
     rng = np.random.default_rng(SEED)
     golden = os.path.join(ROOT, "tests", "golden")
     ft = orc.load_kaldi_feature_transform(os.path.join(golden, "final.feature_transform"))
     ftc = orc.centre_frame_transform(ft)
     eng = Engine(0)
+    eng.set_precision(args.precision)
     N = 57919
     offsets = orc.make_offsets(rng, 192, N)
     x = rng.standard_normal((N, 40)).astype(np.float32)
 
     def report(name, frames, wall, ms, calls, flops_per_frame):
         un = timed.unprofiled_ms
-        print(json.dumps({"config": name, "frames": frames, "ms_per_pass_unprofiled": round(un, 3), "frames_per_s_unprofiled": round(frames / un * 1e3),
+        print(json.dumps({"config": name, "precision": args.precision, "frames": frames, "ms_per_pass_unprofiled": round(un, 3), "frames_per_s_unprofiled": round(frames / un * 1e3),
                           "ms_per_pass": round(wall * 1e3, 3), "frames_per_s": round(frames / wall),
                           "tflops": round(frames * flops_per_frame / wall / 1e12, 2), "kernels_ms": ms, "launches": calls}), flush=True)
 
