@@ -4,6 +4,8 @@
 // activation matrices have M padded to 128 rows and their leading dimension padded to the next layer's K_pad,
 // weights are zero-padded to [N_pad, K_pad].  Wavefront = 64 lanes everywhere.
 #include "am_internal.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace am {
 
@@ -188,10 +190,13 @@ constexpr int GEMM_LDS_256 = 2 * (GEMM_BM + 256) * 32 * 4;  // 128 KiB
 constexpr int GEMM_LDS_384 = 2 * (GEMM_BM + 384) * 16 * 4;  //  80 KiB
 
 hipError_t init_split_kernels();
+hipError_t init_lstm_kernels();
 
 hipError_t init_kernels()
 {
     hipError_t se = init_split_kernels();
+    if (se != hipSuccess) return se;
+    se = init_lstm_kernels();
     if (se != hipSuccess) return se;
     // per device: allow the GEMM's large dynamic LDS
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_f32_kernel<256, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_256);
@@ -677,7 +682,27 @@ constexpr int LSTM_KS = LSTM_KB / 32;     // 16-k sub-steps per wave per batch
 constexpr int LSTM_LDA = LSTM_KB + 4;     // LDS row stride (floats): +16 B -> conflict-free ds_read_b128
 constexpr int LSTM_APT = LSTM_RB * LSTM_KB / 4 / 512;  // 16-B A chunks per thread per batch
 
-__global__ __launch_bounds__(512) void lstm_wavefront_kernel(const LstmWavefrontArgs args)
+template <int NT>
+__device__ __forceinline__ void lstm_batch_mma(const float* sa, const f32x4 (&wc)[LSTM_KS], f32x4 (&acc)[4])
+{
+    f32x4 pb[NT];
+#pragma unroll
+    for (int r = 0; r < NT; ++r) pb[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < LSTM_KS; ++s) {
+        f32x4 a[NT];
+#pragma unroll
+        for (int r = 0; r < NT; ++r) a[r] = *(const f32x4*)(sa + r * 16 * LSTM_LDA + 16 * s);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)   // j outer, row tile inner: consecutive MFMAs hit different accumulators
+#pragma unroll
+            for (int r = 0; r < NT; ++r) pb[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], wc[s][j], pb[r], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < NT; ++r) acc[r] += pb[r];
+}
+
+__global__ __launch_bounds__(512, 4) void lstm_wavefront_kernel(const LstmWavefrontArgs args)
 {
     __shared__ __attribute__((aligned(16))) float sA[LSTM_RB * LSTM_LDA];
     __shared__ float sg[2 * 4 * LSTM_RB * 17];
@@ -751,17 +776,15 @@ __global__ __launch_bounds__(512) void lstm_wavefront_kernel(const LstmWavefront
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (b + 1 < nb) prefetch(b + 1);      // next batch flies while this one is multiplied
-#pragma unroll
-        for (int s = 0; s < LSTM_KS; ++s) {
-            f32x4 a[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < ntile) a[r] = *(const f32x4*)(sA + (r * 16 + l15) * LSTM_LDA + kh * (LSTM_KB / 2) + 16 * s + 4 * lq);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)   // j outer, row tile inner: consecutive MFMAs hit different accumulators
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < ntile) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], wc[s][j], acc[r], 0, 0, 0);
+        // every 64-k chain (this wave's half of the batch) starts from zero and is then folded into the running sum:
+        // the summation order is a property of the K index alone, shared with lstm_thin_kernel, so a frame's
+        // posteriors do not depend on how many utterances happen to share its launch
+        const float* sa = sA + l15 * LSTM_LDA + kh * (LSTM_KB / 2) + 4 * lq;
+        switch (ntile) {
+        case 1: lstm_batch_mma<1>(sa, wc, acc); break;
+        case 2: lstm_batch_mma<2>(sa, wc, acc); break;
+        case 3: lstm_batch_mma<3>(sa, wc, acc); break;
+        default: lstm_batch_mma<4>(sa, wc, acc); break;
         }
     }
     // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
@@ -793,6 +816,129 @@ __global__ __launch_bounds__(512) void lstm_wavefront_kernel(const LstmWavefront
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same step for FEW active utterances (<= 16*R rows per layer; half of the launches of a TIMIT-like file run with
+// <= 16 rows).  The wide kernel above walks K in 8 serial batches, one memory round trip each (1.6 us), on only
+// 32 blocks per layer; with few rows the step is pure latency.  Here K is split over the 8 waves of a block instead and
+// every wave fetches its whole K slice -- weight fragments AND the activation rows, straight into registers, no LDS
+// staging -- in ONE round trip; a block owns 4 units x 4 gates (one 16-column MFMA tile), so a layer is U/4 blocks and
+// the whole chip works on the step.  The 8 partial tiles are summed through LDS in a fixed order.
+//   lane (l15, lq): column l15 = gate l15>>2 of unit 4q + (l15&3); K permutation as above (4 consecutive k per lane).
+// R = 16-row tiles per block, CS = 16-k sub-steps fetched per round trip.
+// ---------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(512) void lstm_thin_kernel(const LstmWavefrontArgs args)
+{
+    extern __shared__ float sp[];                           // [chain][r][16 rows][17]
+    const LstmLayerStep& Ls = args.L[blockIdx.y];
+    const int U_pad = args.U_pad;
+    const int q = blockIdx.x;
+    const int n_active = Ls.n_active;
+    const int tiles = (n_active + 15) >> 4;
+    const int ntile = tiles < R ? tiles : R;
+    if (ntile <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int ldg = 4 * U_pad;
+    const int gcol = (q >> 2) * 64 + 4 * (q & 3);          // + 16*gate + unit-in-quad
+    const int wrow = gcol + 16 * (l15 >> 2) + (l15 & 3);
+    const int first = Ls.first;
+
+    // epilogue operands first (threads tid < 64*R own one (row, unit) each)
+    const int er = tid >> 6, erow = (tid & 63) >> 2, euu = tid & 3, eslot = er * 16 + erow;
+    const bool elive = tid < 64 * R && er < ntile && eslot < n_active;
+    float gpre[4] = {0.f, 0.f, 0.f, 0.f}, cprev = 0.f;
+    if (elive) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            gpre[k] = Ls.G ? Ls.G[(size_t)eslot * ldg + gcol + 16 * k + euu] : Ls.bias[gcol + 16 * k + euu];
+        if (!first) cprev = Ls.Cst[(size_t)eslot * U_pad + 4 * q + euu];
+    }
+
+    const int Kin = Ls.Hin ? Ls.Kin_pad : 0;
+    const int Ktot = Kin + (first ? 0 : U_pad);
+    const int nc = Ktot >> 6;                               // 64-k chains (Ktot is a multiple of 128)
+    const int m = (nc + 7) >> 3;                            // chains per wave: wave w owns [w*m, (w+1)*m)
+    for (int c0 = 0; c0 < m; c0 += 2) {                     // two chains = 8 sub-steps of 16 k per round trip
+        const int ch0 = w * m + c0;
+        const int nch = (ch0 >= nc) ? 0 : ((c0 + 1 < m && ch0 + 1 < nc) ? 2 : 1);
+        f32x4 wv[8], av[R][8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if ((s >> 2) < nch) {
+                const int k0 = ch0 * 64 + s * 16;           // consecutive chains are consecutive in k
+                const float* ap; const float* wp; int ld;
+                if (k0 < Kin) { ld = Ls.Kin_pad; ap = Ls.Hin + k0; wp = Ls.Wup + (size_t)wrow * ld + k0; }
+                else { ld = U_pad; ap = Ls.Hprev + (k0 - Kin); wp = Ls.Wlat + (size_t)wrow * ld + (k0 - Kin); }
+                wv[s] = *(const f32x4*)(wp + 4 * lq);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (r < ntile) av[r][s] = *(const f32x4*)(ap + (size_t)(r * 16 + l15) * ld + 4 * lq);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h < nch) {
+                f32x4 acc[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int s = 4 * h; s < 4 * h + 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (r < ntile) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][s][j], wv[s][j], acc[r], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        sp[(((ch0 + h) * R + r) * 16 + lq * 4 + reg) * 17 + l15] = acc[r][reg];
+            }
+        }
+    }
+    __syncthreads();
+    if (elive) {
+        float pre[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // the wide kernel's order: even chains folded in k order, odd chains likewise, (even + odd) + upward term
+            float ev = 0.0f, od = 0.0f;
+            for (int c = 0; c < nc; c += 2) {
+                ev += sp[((c * R + er) * 16 + erow) * 17 + 4 * k + euu];
+                od += sp[(((c + 1) * R + er) * 16 + erow) * 17 + 4 * k + euu];
+            }
+            pre[k] = (ev + od) + gpre[k];
+        }
+        const float a = tanhf(pre[0]);
+        const float i = am_sigmoid(pre[1]);
+        const float f = am_sigmoid(pre[2]);
+        const float o = am_sigmoid(pre[3]);
+        const float ai = a * i;
+        const float fc = f * cprev;
+        const float cn = ai + fc;
+        const size_t cidx = (size_t)eslot * U_pad + 4 * q + euu;
+        Ls.Cst[cidx] = cn;
+        Ls.Hout[cidx] = o * tanhf(cn);
+    }
+}
+
+constexpr size_t LSTM_THIN_LDS_MAX = 72 * 1024;   // two blocks per CU stay co-resident
+hipError_t init_lstm_kernels()
+{
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_thin_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_THIN_LDS_MAX);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)lstm_thin_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_THIN_LDS_MAX);
+}
+
+static int lstm_thin_mode()
+{
+    static int mode = -1;   // AM_LSTM_THIN=0 disables the few-rows kernel (A/B measurements)
+    if (mode < 0) { const char* v = getenv("AM_LSTM_THIN"); mode = v ? atoi(v) : 1; }
+    return mode;
+}
+
 static int lstm_blocks_for(int n_active, int U_pad, int tpb)
 {
     const int n_ut = U_pad / 16, ut_groups = (n_ut + 7) / 8, n_tiles = (n_active + 15) / 16;
@@ -803,23 +949,58 @@ hipError_t launch_lstm_wavefront(hipStream_t s, LstmWavefrontArgs& a)
 {
     if (a.n <= 0 || a.n > LSTM_MAX_LAYERS || a.U_pad % LSTM_KB) return hipErrorInvalidValue;
     a.ut_groups = (a.U_pad / 16 + 7) / 8;
-    // Row tiles per block (1..4).  More tiles per block reuse each weight fragment more (the launch is L2-bandwidth-bound
-    // with one), fewer keep every CU busy when few utterances are still active.  Up to two blocks are co-resident per
-    // CU, so a launch takes about ceil(blocks / 256) rounds of tpb tile-times: minimise that, with a small penalty per
-    // block for its fixed cost (weight fetch, barriers, gate epilogue).  Measured on 3x512 / 192 utterances: a 288-block
-    // launch at 4 tiles per block (32 CUs carry two blocks) takes 32 us, the same rows as 384 blocks of 3 tiles 21 us.
-    int tpb = 4;
+    for (int l = 0; l < a.n; ++l)
+        if (a.L[l].Hin && a.L[l].Kin_pad % LSTM_KB) return hipErrorInvalidValue;
+    int max_tiles = 0;
+    for (int l = 0; l < a.n; ++l) max_tiles = std::max(max_tiles, (a.L[l].n_active + 15) / 16);
+    if (max_tiles == 0) return hipSuccess;
+    // measured per launch (3x512, graph replay): <= 16 rows 9.4 us thin vs 15 us wide; <= 32 rows 13.5 vs 15.5;
+    // at 33..64 rows the thin form (4 row tiles, A re-read by every block) loses, 18.3 vs 17 us
+    // measured per launch (3x512, graph replay): <= 16 rows 9.4 us thin vs 15 us wide; <= 32 rows 13.5 vs 15.5;
+    // at 33..64 rows the thin form (4 row tiles, A re-read by every block) loses, 18.3 vs 17 us
+    int nc_max = 0;   // 64-k chains of the longest K in this launch: the thin kernel keeps one partial tile per chain in LDS
+    for (int l = 0; l < a.n; ++l)
+        nc_max = std::max(nc_max, ((a.L[l].Hin ? a.L[l].Kin_pad : 0) + (a.L[l].first ? 0 : a.U_pad)) / 64);
+    const size_t thin_lds = (size_t)std::max(nc_max, 2) * max_tiles * 16 * 17 * sizeof(float);
+    if (lstm_thin_mode() && max_tiles <= 2 && thin_lds <= LSTM_THIN_LDS_MAX) {
+        const dim3 grid(a.U_pad / 4, a.n);
+        if (max_tiles == 1) hipLaunchKernelGGL((lstm_thin_kernel<1>), grid, dim3(512), thin_lds, s, a);
+        else hipLaunchKernelGGL((lstm_thin_kernel<2>), grid, dim3(512), thin_lds, s, a);
+        return hipGetLastError();
+    }
+    // Row tiles per block (1..4), chosen per layer.  More tiles per block reuse each weight fragment more, fewer keep
+    // every CU busy when few utterances are still active.  Two blocks are co-resident per CU and share its matrix pipes,
+    // so a launch takes about (blocks per CU) x (tile-times of the costliest block) plus a fixed cost per block (operand
+    // fetch, barriers, gate epilogue; 0.75 tile-times measured); a tile-time is proportional to the layer's K (the
+    // layer fed by the hoisted GEMM multiplies only its lateral half).  Layers with the same K share a choice.
+    // Measured on 3x512 / 192 utterances: 384 blocks of 3 tiles 33 us; 96 blocks of 4 (half K) + 2 x 192 blocks of 2: see DESIGN.md.
+    int Kl[LSTM_MAX_LAYERS], Kmax = 0;
+    for (int l = 0; l < a.n; ++l) {
+        Kl[l] = (a.L[l].Hin ? a.L[l].Kin_pad : 0) + (a.L[l].first ? 0 : a.U_pad);
+        Kmax = std::max(Kmax, Kl[l]);
+    }
+    int tpb_full = 4, tpb_part = 4;   // layers with K == Kmax / with a shorter K
     {
         float best = 1e30f;
-        for (int cand = 4; cand >= 1; --cand) {
-            int blocks = 0;
-            for (int l = 0; l < a.n; ++l) blocks += lstm_blocks_for(a.L[l].n_active, a.U_pad, cand);
-            const float cost = (float)((blocks + 255) / 256) * (cand + 0.75f);
-            if (cost < best - 1e-6f) { best = cost; tpb = cand; }
-        }
+        for (int cf = 4; cf >= 1; --cf)
+            for (int cp = 4; cp >= 1; --cp) {
+                int blocks = 0; float work = 0.0f; bool any_part = false;
+                for (int l = 0; l < a.n; ++l) {
+                    const bool part = Kl[l] < Kmax;
+                    any_part |= part;
+                    const int cand = part ? cp : cf;
+                    blocks += lstm_blocks_for(a.L[l].n_active, a.U_pad, cand);
+                    work = std::max(work, cand * (Kmax > 0 ? (float)Kl[l] / Kmax : 1.0f));
+                }
+                if (!any_part && cp != 4) continue;
+                const int rounds = (blocks + 255) / 256;
+                const float cost = rounds * work + 0.75f * (1.0f + 0.5f * (rounds - 1));
+                if (cost < best - 1e-6f) { best = cost; tpb_full = cf; tpb_part = cp; }
+            }
     }
     int total = 0;
     for (int l = 0; l < a.n; ++l) {
+        const int tpb = Kl[l] < Kmax ? tpb_part : tpb_full;
         const int n_tiles = (a.L[l].n_active + 15) / 16, n_rt = (n_tiles + tpb - 1) / tpb;
         a.L[l].tpb = n_rt > 0 ? (n_tiles + n_rt - 1) / n_rt : 1;   // balanced: ceil(tiles / row blocks)
         a.L[l].block0 = total;

@@ -102,7 +102,7 @@ def main():
             p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
             p.set_members([m])
             p.lstm_upload(x, None, offsets, td)
-            wall, ms, calls = timed(eng, p.lstm_run, args.steps, 1)
+            wall, ms, calls = timed(eng, p.lstm_run, args.steps, 3)  # eager, graph capture, first replay
             fl = 2 * (40 * 2048 + 2 * 512 * 2048 + 3 * 512 * 2048 + 512 * 1909)
             report("3x512 LSTM N=57919 192 utts Tmax=%d timedelay=%d" % (int(np.diff(offsets).max()), td), N, wall, ms, calls, fl)
             p.close()
