@@ -100,6 +100,22 @@ int am_model_create(am_engine* e, int kind, int n_layers, int activation,
                     const int* in_dims, const int* out_dims,
                     const float* const* W, const float* const* b, const float* const* W_lat,
                     am_model** out);
+/* The other recurrent cells get_nn can build (chainer_networks.py:103-161,174-181): they run on the
+ * recurrent path (am_lstm_upload / am_lstm_run / am_forward_lstm) like AM_NET_LSTM models.
+ *   AM_CELL_GRU      "gru" = chainer L.GRU (activation AM_ACT_TANH) and "mgrurelur" = the reference's MGRU with reset gate
+ *                    (MGRU.py:67-85, activation AM_ACT_RELU):  r = sig(W_r x + U_r h), z = sig(W_z x + U_z h),
+ *                    h~ = act(W x + U (r*h)), h' = z*h~ + (1-z)*h; with no previous state: z = sig(W_z x), h' = z*act(W x)
+ *                    (the state Linears and their biases are skipped, MGRU.py:70-84).
+ *                    12 arrays per layer: W_r.W, W_r.b, U_r.W, U_r.b, W_z.W, W_z.b, U_z.W, U_z.b, W.W, W.b, U.W, U.b
+ *   AM_CELL_MGRU     "mgrurelu": the same without reset gate, h~ = act(W x + U h).  8 arrays: W_z.W ... U.b as above.
+ *   AM_CELL_PEEPHOLE "peepholelstm" = chainer StatefulPeepholeLSTM: i,f see peep_i(c), peep_f(c); o sees peep_o(c').
+ *                    6 arrays: upward.W [4U,in], upward.b [4U], lateral.W [4U,U] (gates interleaved a,i,f,o),
+ *                    peep_i.W, peep_f.W, peep_o.W [U,U].
+ * params: n_layers * (12 | 8 | 6) pointers, layer-major, Chainer layout W [out,in], b [out]; layer 0 takes in_dim
+ * inputs, the others `units`.  out_W [n_classes, units], out_b [n_classes]: the output Linear. */
+enum { AM_CELL_LSTM = 0, AM_CELL_GRU = 1, AM_CELL_MGRU = 2, AM_CELL_PEEPHOLE = 3 };
+int am_model_create_rnn(am_engine* e, int cell, int n_layers, int activation, int in_dim, int units, int n_classes,
+                        const float* const* params, const float* out_W, const float* out_b, am_model** out);
 int am_model_destroy(am_model* m);
 
 /* ---- pipeline ------------------------------------------------------------------------------------- */

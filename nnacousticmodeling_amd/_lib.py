@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libamfwd.so")
 
 AM_OK = 0
 AM_NET_FF, AM_NET_LSTM = 0, 1
+AM_CELL_LSTM, AM_CELL_GRU, AM_CELL_MGRU, AM_CELL_PEEPHOLE = 0, 1, 2, 3
 AM_ACT_RELU, AM_ACT_SIGMOID, AM_ACT_TANH = 0, 1, 2
 AM_COMBINE_LOGITS, AM_COMBINE_LOGPOST = 0, 1
 AM_PRECISION_F32, AM_PRECISION_SPLIT_F16 = 0, 1
@@ -44,6 +45,8 @@ SIGNATURES = {
     "am_host_free": (C.c_int, [C.c_void_p]),
     "am_model_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p,
                                   C.POINTER(c_float_p), C.POINTER(c_float_p), C.POINTER(c_float_p), c_void_pp]),
+    "am_model_create_rnn": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(c_float_p), c_float_p, c_float_p, c_void_pp]),
     "am_model_destroy": (C.c_int, [C.c_void_p]),
     "am_pipeline_create": (C.c_int, [C.c_void_p, c_void_pp]),
     "am_pipeline_destroy": (C.c_int, [C.c_void_p]),

@@ -93,11 +93,15 @@ struct Layer {
     float w_scale = 1.f;   // exact power of two applied to W before splitting
     int out_pad_s = 0;     // output width padded to 256
     DevBuf Whi, Wlo, b_s;
+    // other recurrent cells (am_model_create_rnn): packed phase weights and their bias vectors, see RecEpilogue
+    DevBuf WA, WB, bA_first, bA_rest, bB_first, bB_rest;
+    int Kx = 0;            // padded input width of the cell (multiple of 64)
 };
 
 struct am_model {
     am_engine* e = nullptr;
     int kind = 0, n_layers = 0, act = 0;
+    int cell = AM_CELL_LSTM;   // recurrent models: which cell the layers are
     std::vector<Layer> L;  // n_layers + 1 (last = output Linear)
     int in_dim = 0, in_pad = 0, C = 0, C_pad = 0;
     int max_width = 0;     // widest padded hidden activation
@@ -459,8 +463,108 @@ extern "C" int am_model_destroy(am_model* m)
 {
     if (!m) return AM_OK;
     (void)hipSetDevice(m->e->device);
-    for (auto& l : m->L) { l.W.release(); l.b.release(); l.Wlat.release(); l.Whi.release(); l.Wlo.release(); l.b_s.release(); }
+    for (auto& l : m->L) {
+        l.W.release(); l.b.release(); l.Wlat.release(); l.Whi.release(); l.Wlo.release(); l.b_s.release();
+        l.WA.release(); l.WB.release(); l.bA_first.release(); l.bA_rest.release(); l.bB_first.release(); l.bB_rest.release();
+    }
     delete m;
+    return AM_OK;
+}
+
+// Recurrent cells other than L.LSTM.  Chainer layout in, packed per phase for rec_step_kernel:
+// row(unit u, gate g) = 16*(u / NU) + g*NU + u % NU with NU = 16 / gates, columns = [input | state | second state].
+static int cell_param_count(int cell)
+{
+    return cell == AM_CELL_GRU ? 12 : cell == AM_CELL_MGRU ? 8 : cell == AM_CELL_PEEPHOLE ? 6 : 0;
+}
+
+extern "C" int am_model_create_rnn(am_engine* e, int cell, int n_layers, int activation, int in_dim, int units, int n_classes,
+                                   const float* const* params, const float* out_W, const float* out_b, am_model** out)
+{
+    if (!out) return fail(AM_EINVAL, "am_model_create_rnn: out is NULL");
+    *out = nullptr;
+    const int np = cell_param_count(cell);
+    if (!e || !params || !out_W || !out_b) return fail(AM_EINVAL, "am_model_create_rnn: NULL argument");
+    if (np == 0) return fail(AM_EINVAL, "am_model_create_rnn: unknown cell %d", cell);
+    if (n_layers < 1 || n_layers > LSTM_MAX_LAYERS) return fail(AM_EINVAL, "am_model_create_rnn: 1..%d layers are supported", LSTM_MAX_LAYERS);
+    if (in_dim <= 0 || units <= 0 || n_classes <= 0) return fail(AM_EINVAL, "am_model_create_rnn: bad dimension");
+    if (activation < AM_ACT_RELU || activation > AM_ACT_TANH) return fail(AM_EINVAL, "Wrong activation function specified");
+    for (int i = 0; i < n_layers * np; ++i)
+        if (!params[i]) return fail(AM_EINVAL, "am_model_create_rnn: parameter %d of layer %d is NULL", i % np, i / np);
+    HIP_TRY(hipSetDevice(e->device));
+    am_model* m = new am_model();
+    m->e = e; m->kind = AM_NET_LSTM; m->cell = cell; m->n_layers = n_layers; m->act = activation;
+    m->L.resize(n_layers + 1);
+    m->in_dim = in_dim;
+    m->in_pad = (int)round_up(in_dim, 64);
+    m->C = n_classes;
+    m->C_pad = gemm_n_pad(n_classes);
+    const int U = units, U_pad = (int)round_up(U, 64);
+    int rc = AM_OK;
+    for (int l = 0; l < n_layers && rc == AM_OK; ++l) {
+        Layer& Ly = m->L[l];
+        const float* const* P = params + (size_t)l * np;
+        Ly.in = l == 0 ? in_dim : U; Ly.out = U; Ly.U = U; Ly.U_pad = U_pad; Ly.out_pad = U_pad;
+        Ly.Kx = l == 0 ? m->in_pad : U_pad; Ly.in_pad = Ly.Kx;
+        const int in = Ly.in, Kx = Ly.Kx;
+        auto row_of = [](int u, int g, int G) { const int NU = 16 / G; return 16 * (u / NU) + g * NU + u % NU; };
+        if (cell == AM_CELL_GRU || cell == AM_CELL_MGRU) {
+            // Linear pairs (input, state) per gate; GRU: r, z, candidate; MGRU without reset gate: z, candidate
+            const int o = cell == AM_CELL_GRU ? 4 : 0;   // offset of W_z in the parameter list
+            const int ld = Kx + U_pad;
+            auto fill = [&](std::vector<float>& w, std::vector<float>& bf, std::vector<float>& br, int row, int u, const float* Wi, const float* bi, const float* Ws, const float* bs) {
+                memcpy(&w[(size_t)row * ld], Wi + (size_t)u * in, sizeof(float) * in);
+                memcpy(&w[(size_t)row * ld + Kx], Ws + (size_t)u * U, sizeof(float) * U);
+                bf[row] = bi[u];             // no previous state: the state Linear (and its bias) is not applied (MGRU.py:70-76)
+                br[row] = bi[u] + bs[u];
+            };
+            if (cell == AM_CELL_GRU) {
+                std::vector<float> wa((size_t)2 * U_pad * ld, 0.f), af(2 * U_pad, 0.f), ar(2 * U_pad, 0.f);
+                std::vector<float> wb((size_t)U_pad * ld, 0.f), bf(U_pad, 0.f), br(U_pad, 0.f);
+                for (int u = 0; u < U; ++u) {
+                    fill(wa, af, ar, row_of(u, 0, 2), u, P[0], P[1], P[2], P[3]);       // r
+                    fill(wa, af, ar, row_of(u, 1, 2), u, P[4], P[5], P[6], P[7]);       // z
+                    fill(wb, bf, br, u, u, P[8], P[9], P[10], P[11]);                   // candidate: [W | U]
+                }
+                if ((rc = upload(e, Ly.WA, wa)) != AM_OK || (rc = upload(e, Ly.bA_first, af)) != AM_OK || (rc = upload(e, Ly.bA_rest, ar)) != AM_OK) break;
+                if ((rc = upload(e, Ly.WB, wb)) != AM_OK || (rc = upload(e, Ly.bB_first, bf)) != AM_OK || (rc = upload(e, Ly.bB_rest, br)) != AM_OK) break;
+            } else {
+                std::vector<float> wa((size_t)2 * U_pad * ld, 0.f), af(2 * U_pad, 0.f), ar(2 * U_pad, 0.f);
+                for (int u = 0; u < U; ++u) {
+                    fill(wa, af, ar, row_of(u, 0, 2), u, P[o + 0], P[o + 1], P[o + 2], P[o + 3]);   // z
+                    fill(wa, af, ar, row_of(u, 1, 2), u, P[o + 4], P[o + 5], P[o + 6], P[o + 7]);   // candidate
+                }
+                if ((rc = upload(e, Ly.WA, wa)) != AM_OK || (rc = upload(e, Ly.bA_first, af)) != AM_OK || (rc = upload(e, Ly.bA_rest, ar)) != AM_OK) break;
+            }
+        } else {   // AM_CELL_PEEPHOLE: upward.W [4U,in], upward.b [4U], lateral.W [4U,U] (gates interleaved 4u+g), peep_i/f/o.W [U,U]
+            const int ld = Kx + 2 * U_pad;
+            std::vector<float> wa((size_t)4 * U_pad * ld, 0.f), ab(4 * U_pad, 0.f), wb((size_t)U_pad * U_pad, 0.f), zb(U_pad, 0.f);
+            for (int u = 0; u < U; ++u) {
+                for (int g = 0; g < 4; ++g) {
+                    const int row = row_of(u, g, 4), src = 4 * u + g;
+                    memcpy(&wa[(size_t)row * ld], P[0] + (size_t)src * in, sizeof(float) * in);
+                    memcpy(&wa[(size_t)row * ld + Kx], P[2] + (size_t)src * U, sizeof(float) * U);
+                    if (g == 1) memcpy(&wa[(size_t)row * ld + Kx + U_pad], P[3] + (size_t)u * U, sizeof(float) * U);   // peep_i(c)
+                    if (g == 2) memcpy(&wa[(size_t)row * ld + Kx + U_pad], P[4] + (size_t)u * U, sizeof(float) * U);   // peep_f(c)
+                    ab[row] = P[1][src];
+                }
+                memcpy(&wb[(size_t)u * U_pad], P[5] + (size_t)u * U, sizeof(float) * U);                               // peep_o(c')
+            }
+            if ((rc = upload(e, Ly.WA, wa)) != AM_OK || (rc = upload(e, Ly.bA_first, ab)) != AM_OK) break;
+            if ((rc = upload(e, Ly.WB, wb)) != AM_OK || (rc = upload(e, Ly.bB_first, zb)) != AM_OK) break;
+        }
+        m->max_width = std::max(m->max_width, U_pad);
+    }
+    if (rc == AM_OK) {
+        Layer& Lo = m->L[n_layers];
+        Lo.in = U; Lo.out = n_classes; Lo.in_pad = U_pad; Lo.out_pad = gemm_n_pad(n_classes); Lo.out_pad_s = (int)round_up(n_classes, 256);
+        std::vector<float> w((size_t)Lo.out_pad * Lo.in_pad, 0.f), bb(Lo.out_pad, 0.f);
+        for (int o = 0; o < n_classes; ++o) memcpy(&w[(size_t)o * Lo.in_pad], out_W + (size_t)o * U, sizeof(float) * U);
+        memcpy(bb.data(), out_b, sizeof(float) * n_classes);
+        if ((rc = upload(e, Lo.W, w)) == AM_OK) rc = upload(e, Lo.b, bb);
+    }
+    if (rc != AM_OK) { am_model_destroy(m); return rc; }
+    *out = m;
     return AM_OK;
 }
 
@@ -519,7 +623,8 @@ extern "C" int am_pipeline_set_members(am_pipeline* p, int n_members, am_model* 
     if (combine == AM_COMBINE_LOGPOST && has_master) return fail(AM_EINVAL, "am_pipeline_set_members: log-posterior averaging has no master");
     for (int i = 0; i < n_members; ++i) {
         if (!members[i] || members[i]->e != p->e) return fail(AM_EINVAL, "am_pipeline_set_members: member %d is NULL or lives on another engine", i);
-        if (members[i]->kind != members[0]->kind || members[i]->C != members[0]->C || members[i]->in_dim != members[0]->in_dim)
+        if (members[i]->kind != members[0]->kind || members[i]->C != members[0]->C || members[i]->in_dim != members[0]->in_dim ||
+            members[i]->in_pad != members[0]->in_pad)
             return fail(AM_EINVAL, "am_pipeline_set_members: member %d differs in kind / input / output size", i);
     }
     if (members[0]->C > 2048) return fail(AM_EINVAL, "am_pipeline_set_members: at most 2048 classes are supported");
@@ -920,7 +1025,10 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
     AM_TRY(p->d_H.ensure(sizeof(float) * rows_alloc * upad * max_layers));      // one H plane per layer
     HIP_TRY(hipMemsetAsync(p->d_H.p, 0, sizeof(float) * rows_alloc * upad * max_layers, e->stream));
     HIP_TRY(hipMemsetAsync(p->d_G.p, 0, sizeof(float) * rows_alloc * gw, e->stream));
-    AM_TRY(p->d_c.ensure(sizeof(float) * (round_up(std::max(n_utts, 1), 16)) * upad * max_layers));
+    // per layer: the LSTM cell state, or three per-slot planes of the other cells (Z / r*h, or c ping-pong / o), 16 rows of slack
+    const size_t c_bytes = sizeof(float) * 3 * (round_up(std::max(n_utts, 1), 16) + 16) * upad * max_layers;
+    AM_TRY(p->d_c.ensure(c_bytes));
+    HIP_TRY(hipMemsetAsync(p->d_c.p, 0, c_bytes, e->stream));
     AM_TRY(p->d_acc.ensure(sizeof(float) * rows_pad * m0->C_pad));
     if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(p->d_acc2.ensure(sizeof(float) * rows_pad * m0->C_pad));
     AM_TRY(p->d_out.ensure(std::max<size_t>(sizeof(float) * N * m0->C, 16)));
@@ -955,6 +1063,77 @@ extern "C" int am_lstm_run(am_pipeline* p)
     return AM_OK;
 }
 
+// GRU / MGRU / peephole-LSTM stack: wavefront over (layer, time) like the LSTM one, with one or two dependent phases per
+// tick (launch_rec_step).  Tick d runs layer l at t = d - l; cells with a reset gate or an output peephole run phase A of
+// every active layer, then phase B.
+static int rec_stack(am_pipeline* p, am_model* m, size_t h_stride)
+{
+    am_engine* e = p->e;
+    const int NL = m->n_layers, U_pad = m->L[0].U_pad;
+    const int64_t T = (int64_t)p->n_active.size();
+    const size_t plane = (size_t)(round_up(std::max(p->n_slots, 1), 16) + 16) * U_pad;
+    float* Hall = p->d_H.as<float>();
+    float* S = p->d_c.as<float>();
+    const int phases = m->cell == AM_CELL_MGRU ? 1 : 2;
+    for (int64_t d = 0; d < T + NL - 1; ++d)
+        for (int ph = 0; ph < phases; ++ph) {
+            RecStepArgs w{};
+            w.U_pad = U_pad; w.act = m->act;
+            int epi = REC_MGRU;
+            for (int l = 0; l < NL; ++l) {
+                const int64_t t = d - l;
+                if (t < 0 || t >= T) continue;
+                Layer& Ly = m->L[l];
+                RecLayerStep& s = w.L[w.n++];
+                const bool first = t == 0;
+                float* H = Hall + l * h_stride;
+                const float* x = l == 0 ? p->d_in.as<float>() + p->step_off[t] * (int64_t)m->in_pad : Hall + (l - 1) * h_stride + p->step_off[t] * (int64_t)U_pad;
+                const float* hprev = first ? H : H + p->step_off[t - 1] * (int64_t)U_pad;
+                float* hout = H + p->step_off[t] * (int64_t)U_pad;
+                float* S0 = S + (size_t)(3 * l) * plane; float* S1 = S0 + plane; float* S2 = S1 + plane;
+                s.n_active = p->n_active[t]; s.first = first;
+                s.A[0] = x; s.K[0] = Ly.Kx;
+                if (m->cell == AM_CELL_MGRU) {
+                    epi = REC_MGRU;
+                    s.A[1] = hprev; s.K[1] = first ? 0 : U_pad;
+                    s.W = Ly.WA.as<float>(); s.ldw = Ly.Kx + U_pad;
+                    s.bias = (first ? Ly.bA_first : Ly.bA_rest).as<float>();
+                    s.E0 = hprev; s.O0 = hout;
+                } else if (m->cell == AM_CELL_GRU) {
+                    float* Z = S0; float* RH = S1;
+                    s.ldw = Ly.Kx + U_pad;
+                    if (ph == 0) {
+                        epi = REC_GRU_A;
+                        s.A[1] = hprev; s.K[1] = first ? 0 : U_pad;
+                        s.W = Ly.WA.as<float>(); s.bias = (first ? Ly.bA_first : Ly.bA_rest).as<float>();
+                        s.E0 = hprev; s.O0 = Z; s.O1 = RH;
+                    } else {
+                        epi = REC_GRU_B;
+                        s.A[1] = RH; s.K[1] = first ? 0 : U_pad;
+                        s.W = Ly.WB.as<float>(); s.bias = (first ? Ly.bB_first : Ly.bB_rest).as<float>();
+                        s.E0 = hprev; s.E1 = Z; s.O0 = hout;
+                    }
+                } else {   // AM_CELL_PEEPHOLE: c ping-pongs between two planes by time parity (other blocks read c[t-1] as a K segment)
+                    float* Cprev = (t & 1) ? S0 : S1; float* Cnext = (t & 1) ? S1 : S0; float* Opre = S2;
+                    if (ph == 0) {
+                        epi = REC_PEEP_A;
+                        s.A[1] = hprev; s.K[1] = first ? 0 : U_pad;
+                        s.A[2] = Cprev; s.K[2] = first ? 0 : U_pad;
+                        s.W = Ly.WA.as<float>(); s.ldw = Ly.Kx + 2 * U_pad; s.bias = Ly.bA_first.as<float>();
+                        s.E0 = Cprev; s.O0 = Cnext; s.O1 = Opre;
+                    } else {
+                        epi = REC_PEEP_B;
+                        s.A[0] = Cnext; s.K[0] = U_pad;
+                        s.W = Ly.WB.as<float>(); s.ldw = U_pad; s.bias = Ly.bB_first.as<float>();
+                        s.E0 = Cnext; s.E1 = Opre; s.O0 = hout;
+                    }
+                }
+            }
+            AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_rec_step(e->stream, epi, w); }));
+        }
+    return AM_OK;
+}
+
 static int lstm_enqueue(am_pipeline* p)
 {
     am_engine* e = p->e;
@@ -980,11 +1159,13 @@ static int lstm_enqueue(am_pipeline* p)
     AM_TRY(run_kernel(e, K_GATHER_FT, [&] { return launch_gather_ft(e->stream, ga); }));
     for (int mi = 0; mi < (int)p->members.size(); ++mi) {
         am_model* m = p->members[mi];
-        // layer 0: its input is known up front -> hoist the upward projection of ALL frames into one bulk GEMM
         const int NL = m->n_layers;
         const int U_pad = m->L[0].U_pad;
         const size_t h_stride = (size_t)(rows_pad + GEMM_BM) * U_pad;   // per-layer H plane
         const size_t c_stride = (size_t)round_up(std::max(p->n_slots, 1), 16) * U_pad;
+        if (m->cell != AM_CELL_LSTM) AM_TRY(rec_stack(p, m, h_stride));
+        else {
+        // layer 0: its input is known up front -> hoist the upward projection of ALL frames into one bulk GEMM
         {
             Layer& L0 = m->L[0];
             GemmArgs g{};
@@ -1015,7 +1196,8 @@ static int lstm_enqueue(am_pipeline* p)
             }
             AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_wavefront(e->stream, w); }));
         }
-        const float* A = Hall + (size_t)(NL - 1) * h_stride;
+        }
+        const float* A = p->d_H.as<float>() + (size_t)(NL - 1) * h_stride;
         const int lda = U_pad;
         Layer& Lo = m->L[m->n_layers];
         GemmArgs g{};

@@ -112,6 +112,28 @@ struct LstmWavefrontArgs {
 };
 hipError_t launch_lstm_wavefront(hipStream_t s, LstmWavefrontArgs& a);
 
+// Recurrent cells other than L.LSTM (GRU / MGRU / peephole LSTM): one phase of one wavefront tick, see rec_step_kernel.
+enum RecEpilogue {
+    REC_MGRU = 0,    // 2 gates (z, h~):   h = z*act(h~) + (1-z)*h_prev                               (MGRU.py:67-85, no reset gate)
+    REC_GRU_A = 1,   // 2 gates (r, z):    Z = sig(z), RH = sig(r)*h_prev                             (phase A of a cell with reset gate)
+    REC_GRU_B = 2,   // 1 gate  (h~):      h = Z*act(h~) + (1-Z)*h_prev   with h~ over [x | RH]       (phase B)
+    REC_PEEP_A = 3,  // 4 gates (a,i,f,o): c' = tanh(a)*sig(i) + sig(f)*c ; O = o   over [x | h | c]   (phase A of StatefulPeepholeLSTM)
+    REC_PEEP_B = 4   // 1 gate  (peep_o):  h = sig(O + peep_o c') * tanh(c')                          (phase B)
+};
+struct RecLayerStep {
+    const float* A[3]; int K[3];   // K segments of the concatenated operand, each [>= 16-row tiles, K[s]] rows (ld = K[s]); K multiples of 64
+    const float* W; int ldw;       // packed weights [G*U_pad, ldw]: row = 16*tile + gate*(16/G) + unit-in-tile, columns = the segments in order
+    const float* bias;             // [G*U_pad] in the same row order
+    const float* E0; const float* E1;  // element-wise inputs  [slots, U_pad] (see RecEpilogue)
+    float* O0; float* O1;              // element-wise outputs [slots, U_pad]
+    int n_active; int first;
+};
+struct RecStepArgs {
+    RecLayerStep L[LSTM_MAX_LAYERS];
+    int n; int U_pad; int act;     // act: AM_ACT_* of the candidate state (GRU: tanh, MGRU-relu: relu)
+};
+hipError_t launch_rec_step(hipStream_t s, int epilogue, const RecStepArgs& a);
+
 struct ViterbiArgs {
     int P, B, T;                       // phones (start/end nodes), biphone nodes, triphones
     const int* endIdx;                 // [P]

@@ -191,12 +191,15 @@ constexpr int GEMM_LDS_384 = 2 * (GEMM_BM + 384) * 16 * 4;  //  80 KiB
 
 hipError_t init_split_kernels();
 hipError_t init_lstm_kernels();
+hipError_t init_rec_kernels();
 
 hipError_t init_kernels()
 {
     hipError_t se = init_split_kernels();
     if (se != hipSuccess) return se;
     se = init_lstm_kernels();
+    if (se != hipSuccess) return se;
+    se = init_rec_kernels();
     if (se != hipSuccess) return se;
     // per device: allow the GEMM's large dynamic LDS
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_f32_kernel<256, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_256);
@@ -1010,6 +1013,182 @@ hipError_t launch_lstm_wavefront(hipStream_t s, LstmWavefrontArgs& a)
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(lstm_wavefront_kernel, dim3(total), dim3(512), 0, s, a);
     return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Recurrent cells other than L.LSTM: GRU (chainer L.GRU), the reference's MGRU with and without reset
+// gate (MGRU.py:10-85) and StatefulPeepholeLSTM (chainer_networks.py:103-161).  One kernel shape for every cell and phase:
+//   pre[row, col] = sum over the K segments of A_s[row, :] . W[col, segment s]  + bias[col]
+// followed by the cell's element-wise epilogue.  Cells with a reset gate / an output peephole need a second, dependent
+// product inside the step (U(r*h), peep_o(c')): they run as two phases, i.e. two launches per wavefront tick.
+// Geometry as lstm_thin_kernel: a block owns one 16-column MFMA tile = 16/G units x G gates and up to R 16-row tiles;
+// K is cut into 64-k chains dealt to the 8 waves, operands go straight from L2 to registers, the chain partials are
+// folded through LDS in k order (so a frame's result does not depend on which utterances share its launch).
+// grid = (G*U_pad/16 column tiles, layers in this tick, row groups of R tiles).
+// ---------------------------------------------------------------------------------------------------
+template <int G, int EPI, int R>
+__global__ __launch_bounds__(512) void rec_step_kernel(const RecStepArgs args)
+{
+    extern __shared__ float sp[];                           // [chain][r][16 rows][17]
+    constexpr int NU = 16 / G;                              // units per column tile
+    const RecLayerStep& Ls = args.L[blockIdx.y];
+    const int U_pad = args.U_pad;
+    const int tile = blockIdx.x;
+    const int n_active = Ls.n_active;
+    const int row0 = blockIdx.z * R * 16;
+    const int tiles_left = (n_active - row0 + 15) >> 4;
+    const int ntile = tiles_left < R ? tiles_left : R;
+    if (ntile <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int first = Ls.first;
+
+    // element-wise operands of the epilogue first: item = (row tile, row, unit in tile)
+    constexpr int ITEMS = 16 * NU;                          // per row tile
+    const int er = tid / ITEMS, erow = (tid % ITEMS) / NU, euu = tid % NU;
+    const int eslot = row0 + er * 16 + erow;
+    const bool elive = tid < ITEMS * R && er < ntile && eslot < n_active;
+    const size_t eidx = (size_t)eslot * U_pad + tile * NU + euu;
+    float bias[G], e0 = 0.0f, e1 = 0.0f;
+#pragma unroll
+    for (int g = 0; g < G; ++g) bias[g] = 0.0f;
+    if (elive) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) bias[g] = Ls.bias[tile * 16 + g * NU + euu];
+        if (EPI == REC_PEEP_B) { e0 = Ls.E0[eidx]; e1 = Ls.E1[eidx]; }
+        else if (EPI == REC_GRU_B) { e1 = Ls.E1[eidx]; if (!first) e0 = Ls.E0[eidx]; }
+        else if (!first) e0 = Ls.E0[eidx];
+    }
+
+    const int K0 = Ls.K[0], K01 = K0 + Ls.K[1], Ktot = K01 + Ls.K[2];
+    const int nc = Ktot >> 6;                               // 64-k chains
+    const int m = (nc + 7) >> 3;                            // chains per wave: wave w owns [w*m, (w+1)*m)
+    const float* wrow = Ls.W + (size_t)(tile * 16 + l15) * Ls.ldw + 4 * lq;
+    for (int c0 = 0; c0 < m; c0 += 2) {                     // two chains = 8 sub-steps of 16 k per round trip
+        const int ch0 = w * m + c0;
+        const int nch = (ch0 >= nc) ? 0 : ((c0 + 1 < m && ch0 + 1 < nc) ? 2 : 1);
+        f32x4 wv[8], av[R][8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if ((s >> 2) < nch) {
+                const int k0 = ch0 * 64 + s * 16;
+                const float* ap; int ld;
+                if (k0 < K0) { ld = K0; ap = Ls.A[0] + k0; }
+                else if (k0 < K01) { ld = Ls.K[1]; ap = Ls.A[1] + (k0 - K0); }
+                else { ld = Ls.K[2]; ap = Ls.A[2] + (k0 - K01); }
+                wv[s] = *(const f32x4*)(wrow + k0);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (r < ntile) av[r][s] = *(const f32x4*)(ap + (size_t)(row0 + r * 16 + l15) * ld + 4 * lq);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h < nch) {
+                f32x4 acc[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int s = 4 * h; s < 4 * h + 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            if (r < ntile) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r][s][j], wv[s][j], acc[r], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        sp[(((ch0 + h) * R + r) * 16 + lq * 4 + reg) * 17 + l15] = acc[r][reg];
+            }
+        }
+    }
+    __syncthreads();
+    if (!elive) return;
+    float pre[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float sum = 0.0f;
+        for (int c = 0; c < nc; ++c) sum += sp[((c * R + er) * 16 + erow) * 17 + g * NU + euu];
+        pre[g] = sum + bias[g];
+    }
+    if (EPI == REC_MGRU || EPI == REC_GRU_B) {
+        // linear_interpolate(z, h~, h) = z*h~ + (1-z)*h ; without a previous state h = z*h~ (MGRU.py:77-84)
+        const float z = EPI == REC_MGRU ? am_sigmoid(pre[0]) : e1;
+        const float hb = am_activate(pre[G - 1], args.act);
+        float h = z * hb;
+        if (!first) { const float keep = (1.0f - z) * e0; h = h + keep; }
+        Ls.O0[eidx] = h;
+    } else if (EPI == REC_GRU_A) {
+        Ls.O0[eidx] = am_sigmoid(pre[G - 1]);                                   // z
+        Ls.O1[eidx] = first ? 0.0f : am_sigmoid(pre[0]) * e0;                   // r * h_prev
+    } else if (EPI == REC_PEEP_A) {
+        const float a = tanhf(pre[0]);
+        const float i = am_sigmoid(pre[1 % G]);
+        const float f = am_sigmoid(pre[2 % G]);
+        const float ai = a * i;
+        const float fc = f * e0;
+        Ls.O0[eidx] = ai + fc;                                                  // c'
+        Ls.O1[eidx] = pre[3 % G];                                               // o before its peephole term
+    } else {                                                                    // REC_PEEP_B
+        const float o = am_sigmoid(e1 + pre[0]);
+        Ls.O0[eidx] = o * tanhf(e0);
+    }
+}
+
+constexpr size_t REC_LDS_MAX = 72 * 1024;
+
+template <int G, int EPI>
+static hipError_t rec_launch(hipStream_t s, const RecStepArgs& a, int max_tiles, int nc_max)
+{
+    // R = 2 row tiles per block while the chain partials of two tiles fit the LDS budget of two co-resident blocks
+    const int R = (max_tiles >= 2 && (size_t)nc_max * 2 * 16 * 17 * sizeof(float) <= REC_LDS_MAX) ? 2 : 1;
+    const size_t lds = (size_t)std::max(nc_max, 1) * R * 16 * 17 * sizeof(float);
+    if (lds > REC_LDS_MAX) return hipErrorInvalidValue;
+    const dim3 grid(G * a.U_pad / 16, a.n, (max_tiles + R - 1) / R);
+    if (R == 2) hipLaunchKernelGGL((rec_step_kernel<G, EPI, 2>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((rec_step_kernel<G, EPI, 1>), grid, dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int G, int EPI>
+static hipError_t rec_init()
+{
+    hipError_t e = hipFuncSetAttribute((const void*)rec_step_kernel<G, EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)REC_LDS_MAX);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)rec_step_kernel<G, EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)REC_LDS_MAX);
+}
+
+hipError_t init_rec_kernels()
+{
+    hipError_t e;
+    if ((e = rec_init<2, REC_MGRU>()) != hipSuccess) return e;
+    if ((e = rec_init<2, REC_GRU_A>()) != hipSuccess) return e;
+    if ((e = rec_init<1, REC_GRU_B>()) != hipSuccess) return e;
+    if ((e = rec_init<4, REC_PEEP_A>()) != hipSuccess) return e;
+    return rec_init<1, REC_PEEP_B>();
+}
+
+hipError_t launch_rec_step(hipStream_t s, int epilogue, const RecStepArgs& a)
+{
+    if (a.n <= 0 || a.n > LSTM_MAX_LAYERS || a.U_pad % 64) return hipErrorInvalidValue;
+    int max_tiles = 0, nc_max = 0;
+    for (int l = 0; l < a.n; ++l) {
+        const RecLayerStep& L = a.L[l];
+        if (L.K[0] % 64 || L.K[1] % 64 || L.K[2] % 64) return hipErrorInvalidValue;
+        max_tiles = std::max(max_tiles, (L.n_active + 15) / 16);
+        nc_max = std::max(nc_max, (L.K[0] + L.K[1] + L.K[2]) / 64);
+    }
+    if (max_tiles == 0) return hipSuccess;
+    switch (epilogue) {
+    case REC_MGRU: return rec_launch<2, REC_MGRU>(s, a, max_tiles, nc_max);
+    case REC_GRU_A: return rec_launch<2, REC_GRU_A>(s, a, max_tiles, nc_max);
+    case REC_GRU_B: return rec_launch<1, REC_GRU_B>(s, a, max_tiles, nc_max);
+    case REC_PEEP_A: return rec_launch<4, REC_PEEP_A>(s, a, max_tiles, nc_max);
+    case REC_PEEP_B: return rec_launch<1, REC_PEEP_B>(s, a, max_tiles, nc_max);
+    }
+    return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------------------------------

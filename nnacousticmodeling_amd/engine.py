@@ -9,6 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from .networks import RNN_CELLS
 from ._lib import (AM_ACT_RELU, AM_ACT_SIGMOID, AM_ACT_TANH, AM_COMBINE_LOGITS, AM_COMBINE_LOGPOST, AM_NET_FF, AM_NET_LSTM,
                    AmError, c_float_p, c_int64_p, c_int_p, check)
 
@@ -162,8 +163,11 @@ class Model:
                 bs.append(_f32(params["layer_%d/upward/b" % l]))
                 lats.append(_f32(params["layer_%d/lateral/W" % l]))
             _check_gate_layout(bs)
+        elif network in RNN_CELLS:
+            self._create_rnn(engine, network, params)
+            return
         else:
-            raise ValueError("network %r is not supported by the MI355X engine (supported: ff, lstm)" % network)
+            raise ValueError("network %r is not supported by the MI355X engine (supported: ff, lstm, %s)" % (network, ", ".join(RNN_CELLS)))
         ws.append(_f32(params["out/W"]))
         bs.append(_f32(params["out/b"]))
         n = self.layers + 1
@@ -179,6 +183,33 @@ class Model:
         self.in_dim = int(ws[0].shape[1])
         self.num_classes = int(ws[-1].shape[0])
         self.recurrent = network == "lstm"
+
+    def _create_rnn(self, engine, network, params):
+        """gru / mgrurelu / mgrurelur / peepholelstm (am_model_create_rnn; parameter order: networks.RNN_CELLS)."""
+        cell, act, keys = RNN_CELLS[network]
+        arrs = [_f32(params["layer_%d/%s" % (l, k)]) for l in range(self.layers) for k in keys]
+        out_w, out_b = _f32(params["out/W"]), _f32(params["out/b"])
+        first = arrs[keys.index("W_z/W") if "W_z/W" in keys else 0]
+        units = int(out_w.shape[1])
+        in_dim = int(first.shape[1]) if first.ndim == 2 else -1
+        for l in range(self.layers):   # the C side trusts these shapes
+            d = in_dim if l == 0 else units
+            for k, a in zip(keys, arrs[l * len(keys):(l + 1) * len(keys)]):
+                name = k.split("/")[0]
+                rows = 4 * units if name in ("upward", "lateral") else units
+                want = (rows,) if k.endswith("/b") else (rows, d if name in ("upward", "W_r", "W_z", "W") else units)
+                if a.shape != want:
+                    raise ValueError("layer_%d/%s has shape %s, expected %s" % (l, k, a.shape, want))
+        if out_b.shape != (out_w.shape[0],):
+            raise ValueError("out/b has shape %s, expected (%d,)" % (out_b.shape, out_w.shape[0]))
+        p_arr = (c_float_p * len(arrs))(*[_fp(a) for a in arrs])
+        h = C.c_void_p()
+        check(self._lib.am_model_create_rnn(engine._h, cell, self.layers, ACTIVATIONS[act], int(first.shape[1]), units,
+                                            int(out_w.shape[0]), p_arr, _fp(out_w), _fp(out_b), C.byref(h)))
+        self._h = h
+        self.in_dim = int(first.shape[1])
+        self.num_classes = int(out_w.shape[0])
+        self.recurrent = True
 
     def close(self):
         if getattr(self, "_h", None):

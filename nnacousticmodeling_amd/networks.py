@@ -1,4 +1,4 @@
-"""Host-side network descriptions mirroring the reference's model zoo for the in-scope networks.
+"""Host-side network descriptions mirroring the reference's model zoo (every get_nn network except tdnn).
 
 ``get_nn`` / ``is_nn_recurrent`` follow scripts/common/chainer_networks.py:163-187; ``NNWithRPL`` follows
 scripts/common/evaluate.py:19-51; ``RPL4`` follows scripts/common/RPL.py:58-74.  The objects here hold host copies of
@@ -8,12 +8,24 @@ from __future__ import annotations
 
 import numpy as np
 
-SUPPORTED = ("ff", "lstm", "zoneoutlstm", "zoneoutdropoutlstm")
+from ._lib import AM_CELL_GRU, AM_CELL_MGRU, AM_CELL_PEEPHOLE
+
+SUPPORTED = ("ff", "lstm", "zoneoutlstm", "zoneoutdropoutlstm", "gru", "mgrurelu", "mgrurelur", "peepholelstm")
 # At inference (chainer.config.train = False) zoneout returns the new state, so L.StatefulZoneoutLSTM computes exactly
 # what L.LSTM computes (upward Linear + bias-free lateral Linear, interleaved gates, h = None -> zeros on the first step)
 # and its npz keys are the same; both zoneout variants of the reference (chainer_networks.py:64-101) therefore run on the
 # LSTM device path.  Like every network row, this rests on Chainer 3.5 semantics that cannot be pinned here.
 LSTM_EQUIVALENT = ("lstm", "zoneoutlstm", "zoneoutdropoutlstm")
+# The other recurrent cells of the reference's get_nn (chainer_networks.py:174-181).  Per network: the device cell, the
+# candidate activation get_nn hard-wires (L.GRU: tanh; NetMGRU: F.relu whatever --activation says), and the per-layer npz
+# keys in the order am_model_create_rnn takes them.  MGRU.py:10-32 names the Linears W_r/U_r (reset), W_z/U_z (update), W/U.
+_GRU_KEYS = tuple("%s/%s" % (n, k) for n in ("W_r", "U_r", "W_z", "U_z", "W", "U") for k in ("W", "b"))
+RNN_CELLS = {
+    "gru": (AM_CELL_GRU, "tanh", _GRU_KEYS),
+    "mgrurelur": (AM_CELL_GRU, "relu", _GRU_KEYS),
+    "mgrurelu": (AM_CELL_MGRU, "relu", _GRU_KEYS[4:]),
+    "peepholelstm": (AM_CELL_PEEPHOLE, "tanh", ("upward/W", "upward/b", "lateral/W", "peep_i/W", "peep_f/W", "peep_o/W")),
+}
 ALL_REFERENCE_NETWORKS = ("ff", "tdnn", "lstm", "zoneoutlstm", "zoneoutdropoutlstm", "peepholelstm", "gru", "mgrurelu", "mgrurelur")
 
 
@@ -47,6 +59,8 @@ class NetworkSpec:
         for l in range(self.layers):
             if self.network == "ff":
                 keys += ["layer_%d/W" % l, "layer_%d/b" % l]
+            elif self.network in RNN_CELLS:
+                keys += ["layer_%d/%s" % (l, k) for k in RNN_CELLS[self.network][2]]
             else:
                 keys += ["layer_%d/upward/W" % l, "layer_%d/upward/b" % l, "layer_%d/lateral/W" % l]
         return keys + ["out/W", "out/b"]
@@ -59,6 +73,14 @@ class NetworkSpec:
             raise KeyError("%s: missing parameter(s) %s for a %d-layer %s network" % (source, missing, self.layers, self.network))
         p = {k: np.ascontiguousarray(params[k], dtype=np.float32) for k in self.expected_keys()}
         for l in range(self.layers):
+            if self.network in RNN_CELLS and self.network != "peepholelstm":
+                # every Linear of a GRU / MGRU link has `units` outputs; the state Linears are units x units
+                for k in RNN_CELLS[self.network][2]:
+                    v, name = p["layer_%d/%s" % (l, k)], k.split("/")[0]
+                    ok = v.shape == (self.units,) if k.endswith("/b") else (v.shape[0] == self.units and (name.startswith("W") or v.shape[1] == self.units))
+                    if not ok:
+                        raise ValueError("%s: layer_%d/%s has shape %s but --units says %d" % (source, l, k, v.shape, self.units))
+                continue
             if self.network == "ff":
                 w, b = p["layer_%d/W" % l], p["layer_%d/b" % l]
                 want = self.units
@@ -68,6 +90,10 @@ class NetworkSpec:
                 lat = p["layer_%d/lateral/W" % l]
                 if lat.shape != (4 * self.units, self.units):
                     raise ValueError("%s: layer_%d/lateral/W has shape %s, expected %s" % (source, l, lat.shape, (4 * self.units, self.units)))
+                if self.network == "peepholelstm":
+                    for k in ("peep_i/W", "peep_f/W", "peep_o/W"):
+                        if p["layer_%d/%s" % (l, k)].shape != (self.units, self.units):
+                            raise ValueError("%s: layer_%d/%s has shape %s, expected %s" % (source, l, k, p["layer_%d/%s" % (l, k)].shape, (self.units, self.units)))
             if b.shape != (want,) or w.shape[0] != want:
                 raise ValueError("%s: layer %d holds %d outputs but --units says %d" % (source, l, b.shape[0], want))
         if p["out/b"].shape != (self.num_classes,) or p["out/W"].shape[0] != self.num_classes:
@@ -78,7 +104,7 @@ class NetworkSpec:
 
     @property
     def in_dim(self):
-        key = "layer_0/W" if self.network == "ff" else "layer_0/upward/W"
+        key = "layer_0/W" if self.network == "ff" else "layer_0/W_z/W" if self.network in RNN_CELLS and self.network != "peepholelstm" else "layer_0/upward/W"
         if self.layers == 0:
             key = "out/W"
         return int(self.params[key].shape[1])
@@ -112,7 +138,7 @@ def get_nn(network, layers, units, num_classes, activation="relu", tdnn_ksize=No
             raise ValueError("Wrong activation function specified")
         return NetworkSpec(network, layers, units[0] if isinstance(units, (list, tuple)) else units, num_classes, activation)
     if network in ALL_REFERENCE_NETWORKS:
-        raise NotImplementedError("network %r exists in the reference but is outside the MI355X hot-path scope (ff, lstm)" % network)
+        raise NotImplementedError("network %r exists in the reference but is not built here yet (supported: %s)" % (network, ", ".join(SUPPORTED)))
     raise ValueError("Wrong network type specified")
 
 

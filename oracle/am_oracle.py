@@ -247,6 +247,95 @@ class LSTM:
         return _linear(x, self.w_out, self.b_out)
 
 
+class MGRUNet:
+    """Stack of stateful MGRU links + ``out`` (``NetMGRU``, chainer_networks.py:143-161; cell: MGRU.py:35-85), and --
+    with ``use_reset_gate=True, activation="tanh"`` -- chainer's ``L.GRU`` stack (``GRU``, chainer_networks.py:123-141):
+    MGRU.py is chainer's StatefulGRU with the reset gate made optional and the candidate activation a parameter.
+
+    ``z = W_z x``; ``h~ = W x``; with a previous state: ``z += U_z h``, ``h~ += U (r*h)`` where
+    ``r = sig(W_r x + U_r h)`` (or ``h~ += U h`` without reset gate); ``z = sig(z)``; ``h~ = act(h~)``;
+    ``h' = z*h~ + (1-z)*h`` (``linear_interpolate``), or ``z*h~`` on the first step.  Every Linear has a bias; the
+    state Linears -- biases included -- are skipped on the first step (MGRU.py:70-76).  Parity unpinned (Chainer absent)."""
+
+    recurrent = True
+    GATES = ("W_r", "U_r", "W_z", "U_z", "W", "U")
+
+    def __init__(self, params, layers, use_reset_gate=True, activation="tanh", dtype=np.float32):
+        self.layers, self.dtype, self.use_reset_gate = layers, dtype, use_reset_gate
+        self.act = {"relu": lambda v: np.maximum(v, 0), "tanh": np.tanh, "sigmoid": _sigmoid}[activation]
+        names = self.GATES if use_reset_gate else self.GATES[2:]
+        self.lin = [{n: (np.asarray(params["layer_%d/%s/W" % (l, n)], dtype=dtype), np.asarray(params["layer_%d/%s/b" % (l, n)], dtype=dtype))
+                     for n in names} for l in range(layers)]
+        self.w_out = np.asarray(params["out/W"], dtype=dtype)
+        self.b_out = np.asarray(params["out/b"], dtype=dtype)
+        self.reset_state()
+
+    def reset_state(self):
+        self.h = [None] * self.layers
+
+    def __call__(self, x):
+        x = np.asarray(x, dtype=self.dtype)
+        one = self.dtype(1)
+        for l in range(self.layers):
+            L, h = self.lin[l], self.h[l]
+            z = _linear(x, *L["W_z"])
+            h_bar = _linear(x, *L["W"])
+            if h is not None:
+                z += _linear(h, *L["U_z"])
+                if self.use_reset_gate:
+                    r = _sigmoid(_linear(x, *L["W_r"]) + _linear(h, *L["U_r"]))
+                    h_bar += _linear(r * h, *L["U"])
+                else:
+                    h_bar += _linear(h, *L["U"])
+            z = _sigmoid(z)
+            h_bar = self.act(h_bar)
+            self.h[l] = z * h_bar + (one - z) * h if h is not None else z * h_bar
+            x = self.h[l]
+        return _linear(x, self.w_out, self.b_out)
+
+
+class PeepholeLSTM:
+    """Stack of chainer ``L.StatefulPeepholeLSTM`` links + ``out`` (chainer_networks.py:103-121).  Chainer 3.5 semantics
+    (source not in the container, parity unpinned): ``g = upward(x) [+ lateral(h)]``, gates interleaved a,i,f,o as in
+    ``L.LSTM``; ``i = sig(i + peep_i(c))``, ``f = sig(f + peep_f(c))``, ``c' = tanh(a)*i + f*c``,
+    ``o = sig(o + peep_o(c'))``, ``h' = o*tanh(c')``; the three peepholes are bias-free U x U Linears; c starts at 0."""
+
+    recurrent = True
+
+    def __init__(self, params, layers, dtype=np.float32):
+        self.layers, self.dtype = layers, dtype
+        g = lambda l, k: np.asarray(params["layer_%d/%s" % (l, k)], dtype=dtype)  # noqa: E731
+        self.p = [{k: g(l, k) for k in ("upward/W", "upward/b", "lateral/W", "peep_i/W", "peep_f/W", "peep_o/W")} for l in range(layers)]
+        self.w_out = np.asarray(params["out/W"], dtype=dtype)
+        self.b_out = np.asarray(params["out/b"], dtype=dtype)
+        self.reset_state()
+
+    def reset_state(self):
+        self.h = [None] * self.layers
+        self.c = [None] * self.layers
+
+    def __call__(self, x):
+        x = np.asarray(x, dtype=self.dtype)
+        for l in range(self.layers):
+            P = self.p[l]
+            g = _linear(x, P["upward/W"], P["upward/b"])
+            if self.h[l] is not None:
+                g += self.h[l].dot(P["lateral/W"].T)
+            if self.c[l] is None:
+                self.c[l] = np.zeros((x.shape[0], g.shape[1] // 4), dtype=self.dtype)
+            r = g.reshape(g.shape[0], g.shape[1] // 4, 4)
+            c = self.c[l]
+            a = np.tanh(r[:, :, 0])
+            i = _sigmoid(r[:, :, 1] + c.dot(P["peep_i/W"].T))
+            f = _sigmoid(r[:, :, 2] + c.dot(P["peep_f/W"].T))
+            c_next = a * i + f * c
+            o = _sigmoid(r[:, :, 3] + c_next.dot(P["peep_o/W"].T))
+            self.c[l] = c_next
+            self.h[l] = o * np.tanh(c_next)
+            x = self.h[l]
+        return _linear(x, self.w_out, self.b_out)
+
+
 class RPL4:
     """``RPL4.__call__`` (RPL.py:58-74): log_softmax -> x + x*W + b -> log-add-exp with floor ``lb``."""
 
@@ -309,8 +398,16 @@ def get_nn(network, layers, params, activation="relu", dtype=np.float32):
     """``get_nn`` restricted to the in-scope networks (chainer_networks.py:163-184)."""
     if network == "ff":
         return MLP(params, layers, activation, dtype)
-    if network == "lstm":
+    if network in ("lstm", "zoneoutlstm", "zoneoutdropoutlstm"):   # zoneout is the identity at inference
         return LSTM(params, layers, dtype)
+    if network == "gru":
+        return MGRUNet(params, layers, True, "tanh", dtype)
+    if network == "mgrurelu":
+        return MGRUNet(params, layers, False, "relu", dtype)
+    if network == "mgrurelur":
+        return MGRUNet(params, layers, True, "relu", dtype)
+    if network == "peepholelstm":
+        return PeepholeLSTM(params, layers, dtype)
     raise ValueError("network %r is outside the hot-path scope" % network)
 
 
@@ -470,6 +567,30 @@ def make_lstm_params(rng, in_dim, units, layers, n_out, bias_scale=0.1):
         d = units
     p["out/W"] = (rng.standard_normal((n_out, d)) / np.sqrt(d)).astype(np.float32)
     p["out/b"] = (bias_scale * rng.standard_normal(n_out)).astype(np.float32)
+    return p
+
+
+def make_gru_params(rng, in_dim, units, layers, n_out, reset_gate=True, bias_scale=0.1):
+    """Synthetic parameters of a GRU / MGRU stack in Chainer's key layout (layer_{l}/{W_r,U_r,W_z,U_z,W,U}/{W,b})."""
+    p = {}
+    d = in_dim
+    for l in range(layers):
+        for name in (("W_r", "U_r") if reset_gate else ()) + ("W_z", "U_z", "W", "U"):
+            k = d if name.startswith("W") else units
+            p["layer_%d/%s/W" % (l, name)] = (rng.standard_normal((units, k)) / np.sqrt(k)).astype(np.float32)
+            p["layer_%d/%s/b" % (l, name)] = (bias_scale * rng.standard_normal(units)).astype(np.float32)
+        d = units
+    p["out/W"] = (rng.standard_normal((n_out, d)) / np.sqrt(d)).astype(np.float32)
+    p["out/b"] = (bias_scale * rng.standard_normal(n_out)).astype(np.float32)
+    return p
+
+
+def make_peephole_params(rng, in_dim, units, layers, n_out, bias_scale=0.1):
+    """Synthetic parameters of a StatefulPeepholeLSTM stack (upward, lateral, peep_i, peep_f, peep_o)."""
+    p = make_lstm_params(rng, in_dim, units, layers, n_out, bias_scale)
+    for l in range(layers):
+        for name in ("peep_i", "peep_f", "peep_o"):
+            p["layer_%d/%s/W" % (l, name)] = (0.5 * rng.standard_normal((units, units)) / np.sqrt(units)).astype(np.float32)
     return p
 
 

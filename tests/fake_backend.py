@@ -27,7 +27,7 @@ class Engine:
 class Model:
     def __init__(self, engine, network, layers, params, activation="relu"):
         self.net = orc.get_nn(network, layers, params, activation)
-        self.recurrent = network == "lstm"
+        self.recurrent = orc.is_nn_recurrent(network)
         self.num_classes = params["out/W"].shape[0]
 
     def close(self):

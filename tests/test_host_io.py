@@ -69,7 +69,10 @@ def test_get_nn_scope():
     assert networks.is_nn_recurrent("lstm") and networks.is_nn_recurrent("zoneoutlstm") and networks.is_nn_recurrent("gru")
     assert networks.is_nn_recurrent("mgrurelu") and not networks.is_nn_recurrent("ff") and not networks.is_nn_recurrent("tdnn")
     with pytest.raises(NotImplementedError):
-        networks.get_nn("gru", 2, [64], 1909)
+        networks.get_nn("tdnn", 2, [64, 64], 1909, "relu", [5, 5])
+    for name, n_keys in (("gru", 12), ("mgrurelur", 12), ("mgrurelu", 8), ("peepholelstm", 6)):
+        spec = networks.get_nn(name, 2, [64], 1909, "sigmoid")   # the cells' own activations are hard-wired (chainer_networks.py:174-181)
+        assert spec.network == name and spec.recurrent and len(spec.expected_keys()) == 2 * n_keys + 2
     z = networks.get_nn("zoneoutlstm", 2, [64], 1909, "relu", [5], [0.5, 0.5])  # inference-equivalent to lstm
     assert z.network == "lstm" and z.reference_network == "zoneoutlstm" and z.recurrent
     with pytest.raises(ValueError):

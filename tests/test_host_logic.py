@@ -135,22 +135,27 @@ def test_predict_folds_cli_per_fold_and_dev(tmp_path, fake_runners, real_ft_path
     assert ei.value.code == 2
 
 
-def test_predict_folds_cli_lstm_timedelay(tmp_path, fake_runners, real_ft_path):
+@pytest.mark.parametrize("network", ["lstm", "zoneoutlstm", "gru", "mgrurelu", "mgrurelur", "peepholelstm"])
+def test_predict_folds_cli_recurrent_timedelay(tmp_path, fake_runners, real_ft_path, network):
+    """Every recurrent network of the reference's get_nn through the CLI: npz keys, loader, runner, time-delay shift."""
     rng = np.random.default_rng(5)
     data_dir, model_dir, out_dir = (tmp_path / d for d in ("data", "models", "out"))
     data_dir.mkdir(), model_dir.mkdir()
     _write_ft(data_dir / "final.feature_transform", real_ft_path)
     ft = orc.centre_frame_transform(orc.load_kaldi_feature_transform(real_ft_path))
-    params = orc.make_lstm_params(rng, 40, 16, 2, 39)
+    if network.endswith("lstm"):
+        params = (orc.make_peephole_params if network == "peepholelstm" else orc.make_lstm_params)(rng, 40, 16, 2, 39)
+    else:
+        params = orc.make_gru_params(rng, 40, 16, 2, 39, reset_gate=network != "mgrurelu")
     chainer_npz.write_npz(model_dir / "fold_0.npz", params)
     off = orc.make_offsets(rng, 5, 60, lo=4, hi=25)
     x = rng.standard_normal((60, 40)).astype(np.float32)
     np.save(data_dir / "data_0.npy", x)
     np.save(data_dir / "offsets_0.npy", off.astype(np.int32))  # fold offsets are int32 (generate_folds.py:101)
-    predict_folds.main(["-n", "lstm", "-l", 2, "-u", 16, "-d", 0.2, "--timedelay", 3, "--ft", "final.feature_transform", "--data-dir", data_dir,
+    predict_folds.main(["-n", network, "-l", 2, "-u", 16, "-d", 0.2, 0.2, "--timedelay", 3, "--ft", "final.feature_transform", "--data-dir", data_dir,
                         "--fold-data-dir", data_dir, "--fold-model-dir", model_dir, "--fold-output-dir", out_dir, "--no-progress"])
     got = np.load(out_dir / "data_0.npy")
-    want = orc.predict(orc.LSTM(params, 2), x, off, True, 1, 3, ft)
+    want = orc.predict(orc.get_nn(network, 2, params), x, off, True, 1, 3, ft)
     assert got.shape == (60, 39) and np.max(np.abs(got - want)) < 1e-5
 
 

@@ -106,6 +106,24 @@ def main():
             fl = 2 * (40 * 2048 + 2 * 512 * 2048 + 3 * 512 * 2048 + 512 * 1909)
             report("3x512 LSTM N=57919 192 utts Tmax=%d timedelay=%d" % (int(np.diff(offsets).max()), td), N, wall, ms, calls, fl)
             p.close()
+    if args.which in ("all", "cells"):
+        # the other recurrent cells of get_nn at the LSTM config's size
+        for net in ("gru", "mgrurelu", "peepholelstm"):
+            if net == "peepholelstm":
+                params = orc.make_peephole_params(rng, 40, 512, 3, 1909)
+                fl = 2 * (40 * 2048 + 2 * 512 * 2048 + 3 * 512 * 2048 + 3 * 3 * 512 * 512 + 512 * 1909)
+            else:
+                g = 2 if net == "mgrurelu" else 3
+                params = orc.make_gru_params(rng, 40, 512, 3, 1909, reset_gate=net != "mgrurelu")
+                fl = 2 * (g * (40 * 512 + 2 * 512 * 512 + 3 * 512 * 512) + 512 * 1909)
+            m = Model(eng, net, 3, params)
+            p = Pipeline(eng)
+            p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
+            p.set_members([m])
+            p.lstm_upload(x, None, offsets, 0)
+            wall, ms, calls = timed(eng, p.lstm_run, args.steps, 3)
+            report("3x512 %s N=57919 192 utts Tmax=%d" % (net, int(np.diff(offsets).max())), N, wall, ms, calls, fl)
+            p.close()
     if args.which in ("all", "ens"):
         plist = [orc.make_mlp_params(rng, 440, 1024, 4, 1909) for _ in range(10)]
         models = [Model(eng, "ff", 4, q) for q in plist]
