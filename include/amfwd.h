@@ -113,6 +113,15 @@ int am_model_create(am_engine* e, int kind, int n_layers, int activation,
  *                    peep_i.W, peep_f.W, peep_o.W [U,U].
  * params: n_layers * (12 | 8 | 6) pointers, layer-major, Chainer layout W [out,in], b [out]; layer 0 takes in_dim
  * inputs, the others `units`.  out_W [n_classes, units], out_b [n_classes]: the output Linear. */
+/* "tdnn" (chainer_networks.py:24-42): n_layers Convolution2D (1, ksize[l]) over the window of
+ * win = sum(ksize) - n_layers + 1 positions, then the output Linear on the one remaining position.  A feed-forward model:
+ * it runs through am_ff_upload / am_ff_run / am_forward_ff behind a frontend of `win` shifts and no i-vectors.  The
+ * reference views each spliced row of win*D values as [D channels][win positions] (F.reshape(x, (B, -1, 1, win))): channel
+ * c, position p is element c*win + p of the row -- reproduced here.  W[l]: [units[l], in_channels_l, 1, ksize[l]]
+ * (in_channels_0 = in_channels = D, then units[l-1]), b[l]: [units[l]]; out_W: [n_classes, units[n_layers-1]]. */
+int am_model_create_tdnn(am_engine* e, int n_layers, int activation, int in_channels, const int* units, const int* ksize,
+                         const float* const* W, const float* const* b, const float* out_W, const float* out_b, int n_classes,
+                         am_model** out);
 enum { AM_CELL_LSTM = 0, AM_CELL_GRU = 1, AM_CELL_MGRU = 2, AM_CELL_PEEPHOLE = 3 };
 int am_model_create_rnn(am_engine* e, int cell, int n_layers, int activation, int in_dim, int units, int n_classes,
                         const float* const* params, const float* out_W, const float* out_b, am_model** out);

@@ -45,6 +45,8 @@ SIGNATURES = {
     "am_host_free": (C.c_int, [C.c_void_p]),
     "am_model_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p,
                                   C.POINTER(c_float_p), C.POINTER(c_float_p), C.POINTER(c_float_p), c_void_pp]),
+    "am_model_create_tdnn": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, C.POINTER(c_float_p), C.POINTER(c_float_p),
+                                       c_float_p, c_float_p, C.c_int, c_void_pp]),
     "am_model_create_rnn": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(c_float_p), c_float_p, c_float_p, c_void_pp]),
     "am_model_destroy": (C.c_int, [C.c_void_p]),

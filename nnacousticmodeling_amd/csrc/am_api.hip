@@ -102,6 +102,11 @@ struct am_model {
     am_engine* e = nullptr;
     int kind = 0, n_layers = 0, act = 0;
     int cell = AM_CELL_LSTM;   // recurrent models: which cell the layers are
+    // TDNN (am_model_create_tdnn): a feed-forward model whose hidden layers are (1,k) convolutions over a window of
+    // `win` positions; layer l maps pos[l] positions x chan[l] channels to pos[l+1] x chan[l+1] (chan = padded widths)
+    bool tdnn = false;
+    int win = 0, tdnn_D = 0;
+    std::vector<int> ksize, pos, chan;
     std::vector<Layer> L;  // n_layers + 1 (last = output Linear)
     int in_dim = 0, in_pad = 0, C = 0, C_pad = 0;
     int max_width = 0;     // widest padded hidden activation
@@ -473,6 +478,61 @@ extern "C" int am_model_destroy(am_model* m)
 
 // Recurrent cells other than L.LSTM.  Chainer layout in, packed per phase for rec_step_kernel:
 // row(unit u, gate g) = 16*(u / NU) + g*NU + u % NU with NU = 16 / gates, columns = [input | state | second state].
+extern "C" int am_model_create_tdnn(am_engine* e, int n_layers, int activation, int in_channels, const int* units, const int* ksize,
+                                    const float* const* W, const float* const* b, const float* out_W, const float* out_b, int n_classes,
+                                    am_model** out)
+{
+    if (!out) return fail(AM_EINVAL, "am_model_create_tdnn: out is NULL");
+    *out = nullptr;
+    if (!e || !units || !ksize || !W || !b || !out_W || !out_b) return fail(AM_EINVAL, "am_model_create_tdnn: NULL argument");
+    if (n_layers < 1 || n_layers > 64) return fail(AM_EINVAL, "am_model_create_tdnn: bad layer count %d", n_layers);
+    if (activation < AM_ACT_RELU || activation > AM_ACT_TANH) return fail(AM_EINVAL, "Wrong activation function specified");
+    if (in_channels <= 0 || n_classes <= 0) return fail(AM_EINVAL, "am_model_create_tdnn: bad dimension");
+    int win = 1;
+    for (int l = 0; l < n_layers; ++l) {
+        if (units[l] <= 0 || ksize[l] <= 0 || !W[l] || !b[l]) return fail(AM_EINVAL, "am_model_create_tdnn: layer %d malformed", l);
+        win += ksize[l] - 1;   // input_win_size = sum(ksize) - len(ksize) + 1 (chainer_networks.py:32): the last layer sees one position
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    am_model* m = new am_model();
+    m->e = e; m->kind = AM_NET_FF; m->tdnn = true; m->n_layers = n_layers; m->act = activation;
+    m->win = win; m->tdnn_D = in_channels;
+    m->in_dim = in_channels * win;
+    m->in_pad = (int)round_up(in_channels, 32);   // channels per position of the channel-last input
+    m->C = n_classes; m->C_pad = gemm_n_pad(n_classes);
+    m->L.resize(n_layers + 1);
+    m->ksize.assign(ksize, ksize + n_layers);
+    m->pos.assign(1, win); m->chan.assign(1, m->in_pad);
+    int rc = AM_OK, cin = in_channels;
+    for (int l = 0; l < n_layers && rc == AM_OK; ++l) {
+        Layer& Ly = m->L[l];
+        const int k = ksize[l], cp = m->chan[l];
+        Ly.in = cin * k; Ly.out = units[l]; Ly.in_pad = cp * k; Ly.out_pad = gemm_n_pad(units[l]);
+        // Convolution2D weight [out, in, 1, k] (cross-correlation) -> GEMM weight over the window's taps: column j*cp + c
+        std::vector<float> w((size_t)Ly.out_pad * Ly.in_pad, 0.f), bb(Ly.out_pad, 0.f);
+        for (int o = 0; o < units[l]; ++o)
+            for (int c = 0; c < cin; ++c)
+                for (int j = 0; j < k; ++j) w[(size_t)o * Ly.in_pad + (size_t)j * cp + c] = W[l][((size_t)o * cin + c) * k + j];
+        memcpy(bb.data(), b[l], sizeof(float) * units[l]);
+        if ((rc = upload(e, Ly.W, w)) != AM_OK || (rc = upload(e, Ly.b, bb)) != AM_OK) break;
+        m->pos.push_back(m->pos[l] - k + 1);
+        m->chan.push_back(Ly.out_pad);
+        m->max_width = std::max(m->max_width, Ly.out_pad);
+        cin = units[l];
+    }
+    if (rc == AM_OK) {
+        Layer& Lo = m->L[n_layers];   // out Linear on the flattened (units, 1, 1) map
+        Lo.in = cin; Lo.out = n_classes; Lo.in_pad = m->chan[n_layers]; Lo.out_pad = gemm_n_pad(n_classes);
+        std::vector<float> w((size_t)Lo.out_pad * Lo.in_pad, 0.f), bb(Lo.out_pad, 0.f);
+        for (int o = 0; o < n_classes; ++o) memcpy(&w[(size_t)o * Lo.in_pad], out_W + (size_t)o * cin, sizeof(float) * cin);
+        memcpy(bb.data(), out_b, sizeof(float) * n_classes);
+        if ((rc = upload(e, Lo.W, w)) == AM_OK) rc = upload(e, Lo.b, bb);
+    }
+    if (rc != AM_OK) { am_model_destroy(m); return rc; }
+    *out = m;
+    return AM_OK;
+}
+
 static int cell_param_count(int cell)
 {
     return cell == AM_CELL_GRU ? 12 : cell == AM_CELL_MGRU ? 8 : cell == AM_CELL_PEEPHOLE ? 6 : 0;
@@ -624,7 +684,7 @@ extern "C" int am_pipeline_set_members(am_pipeline* p, int n_members, am_model* 
     for (int i = 0; i < n_members; ++i) {
         if (!members[i] || members[i]->e != p->e) return fail(AM_EINVAL, "am_pipeline_set_members: member %d is NULL or lives on another engine", i);
         if (members[i]->kind != members[0]->kind || members[i]->C != members[0]->C || members[i]->in_dim != members[0]->in_dim ||
-            members[i]->in_pad != members[0]->in_pad)
+            members[i]->in_pad != members[0]->in_pad || members[i]->tdnn != members[0]->tdnn || members[i]->win != members[0]->win)
             return fail(AM_EINVAL, "am_pipeline_set_members: member %d differs in kind / input / output size", i);
     }
     if (members[0]->C > 2048) return fail(AM_EINVAL, "am_pipeline_set_members: at most 2048 classes are supported");
@@ -737,6 +797,52 @@ static int final_finish(am_pipeline* p, int64_t rows, float* out, const int* row
 // ----------------------------------------------------------------------------------------------------
 // feed-forward path
 // ----------------------------------------------------------------------------------------------------
+// TDNN geometry.  Layer l's input is a channel-last matrix of (frames * pos[l]) rows x chan[l]; its GEMM computes
+// round_up(frames * pos[l+1], 256) output rows, row R reading input rows [R + (R / pos[l+1]) * (k-1), ... + k).
+static int64_t tdnn_chunk_frames(const am_model* m)
+{
+    const int64_t f = FF_CHUNK_ROWS / std::max(m->win, 1) / GEMM_BM * GEMM_BM;
+    return std::max<int64_t>(GEMM_BM, f);
+}
+
+static size_t tdnn_rows_needed(const am_model* m, int l, int64_t frames)
+{
+    // rows of layer l's INPUT buffer (l = 0: the frontend's output; l = n_layers: the out Linear's input)
+    size_t rows = (size_t)round_up(frames * m->pos[l], GEMM_BM);
+    if (l < m->n_layers) {
+        const int64_t R = round_up(frames * m->pos[l + 1], GEMM_BM) - 1;
+        rows = std::max(rows, (size_t)(R + R / m->pos[l + 1] * (m->ksize[l] - 1) + m->ksize[l] + 1));
+    }
+    return rows + 1;
+}
+
+static int tdnn_member_forward(am_pipeline* p, int mi, int64_t frames, float* acc)
+{
+    am_engine* e = p->e;
+    am_model* m = p->members[mi];
+    const float* A = p->d_in.as<float>();
+    for (int l = 0; l <= m->n_layers; ++l) {
+        Layer& Ly = m->L[l];
+        GemmArgs g{};
+        g.A = A; g.lda = m->chan[l]; g.W = Ly.W.as<float>(); g.ldw = Ly.in_pad; g.bias = Ly.b.as<float>();
+        g.N_pad = Ly.out_pad; g.K_pad = Ly.in_pad; g.act = m->act;
+        int id;
+        if (l < m->n_layers) {
+            g.M_pad = (int)round_up(frames * m->pos[l + 1], GEMM_BM);
+            g.row_p = m->pos[l + 1]; g.row_skip = m->ksize[l] - 1;
+            g.C = ((l & 1) ? p->d_act1 : p->d_act0).as<float>(); g.ldc = Ly.out_pad; g.epi = EPI_ACT; g.alpha = 1.f;
+            id = K_GEMM_HIDDEN;
+        } else {
+            g.M_pad = (int)round_up(frames, GEMM_BM);   // pos[n_layers] == 1: one row per frame
+            g.C = acc; g.ldc = m->C_pad; g.epi = epilogue_mode(p, mi, &g.alpha);
+            id = K_GEMM_OUT;
+        }
+        AM_TRY(run_kernel(e, id, [&] { return launch_gemm(e->stream, g); }));
+        A = g.C;
+    }
+    return AM_OK;
+}
+
 extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, int64_t n, int halo_lo, int halo_hi)
 {
     AM_TRY(check_ready(p, AM_NET_FF));
@@ -757,15 +863,35 @@ extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, i
         AM_TRY(p->d_ivec.ensure(std::max<size_t>(sizeof(float) * n * p->d_iv, 16)));
         if (n > 0) HIP_TRY(hipMemcpyAsync(p->d_ivec.p, ivec, sizeof(float) * n * p->d_iv, hipMemcpyHostToDevice, e->stream));
     }
+    if (m0->tdnn && (p->D != m0->tdnn_D || p->n_shifts != m0->win))
+        return fail(AM_EINVAL, "am_ff_upload: the TDNN expects %d channels x %d positions, the frontend splices %d x %d", m0->tdnn_D, m0->win, p->D, p->n_shifts);
+    if (m0->tdnn) {
+        // frames per chunk are cut so that the widest activation ((frames * positions) rows) stays near the FF chunk size;
+        // every buffer gets slack rows for the windows of the padded GEMM rows (tdnn_rows_needed)
+        if (p->d_iv > 0) return fail(AM_EINVAL, "am_ff_upload: TDNN members take no i-vectors");
+        const int64_t frames = std::min<int64_t>(round_up(std::max<int64_t>(n, 1), GEMM_BM), tdnn_chunk_frames(m0));
+        size_t in_rows = 0, act_elems = 0;
+        for (auto* m : p->members) {
+            in_rows = std::max(in_rows, tdnn_rows_needed(m, 0, frames));
+            for (int l = 1; l <= m->n_layers; ++l) act_elems = std::max(act_elems, tdnn_rows_needed(m, l, frames) * (size_t)m->chan[l]);
+        }
+        AM_TRY(p->d_in.ensure(sizeof(float) * in_rows * m0->in_pad));
+        AM_TRY(p->d_act0.ensure(sizeof(float) * act_elems));
+        AM_TRY(p->d_act1.ensure(sizeof(float) * act_elems));
+        HIP_TRY(hipMemsetAsync(p->d_in.p, 0, sizeof(float) * in_rows * m0->in_pad, e->stream));   // slack rows are read (x 0 weights): keep them finite
+        HIP_TRY(hipMemsetAsync(p->d_act0.p, 0, sizeof(float) * act_elems, e->stream));
+        HIP_TRY(hipMemsetAsync(p->d_act1.p, 0, sizeof(float) * act_elems, e->stream));
+    } else {
     AM_TRY(p->d_in.ensure(sizeof(float) * rows * m0->in_pad));
     if (width > 0) {
         AM_TRY(p->d_act0.ensure(sizeof(float) * rows * width));
         AM_TRY(p->d_act1.ensure(sizeof(float) * rows * width));
     }
+    }
     const int acc_w = std::max<int>(m0->C_pad, (int)round_up(m0->C, 256));
     AM_TRY(p->d_acc.ensure(sizeof(float) * rows * acc_w));
     if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(p->d_acc2.ensure(sizeof(float) * rows * acc_w));
-    AM_TRY(p->d_in_s.ensure(sizeof(float) * rows * m0->in_pad));
+    if (!m0->tdnn) AM_TRY(p->d_in_s.ensure(sizeof(float) * rows * m0->in_pad));
     AM_TRY(p->d_out.ensure(std::max<size_t>(sizeof(float) * n * m0->C, 16)));
     AM_TRY(sync_all(e));
     p->n = n; p->halo_lo = halo_lo; p->halo_hi = halo_hi; p->has_ivec = ivec != nullptr;
@@ -805,6 +931,7 @@ static int ff_member_forward(am_pipeline* p, int mi, int64_t rows_pad, float* ac
 static int ensure_split_weights(am_model* m)
 {
     if (m->split_state != 0) return AM_OK;
+    if (m->tdnn) { m->split_state = -1; return AM_OK; }
     am_engine* e = m->e;
     for (int l = 0; l < m->n_layers; ++l)
         if (m->L[l].out_pad % 256) { m->split_state = -1; return AM_OK; }
@@ -830,7 +957,7 @@ static int ensure_split_weights(am_model* m)
 static bool use_split(am_pipeline* p)
 {
     if (p->e->precision != AM_PRECISION_SPLIT_F16) return false;
-    for (auto* m : p->members) if (m->split_state != 1) return false;
+    for (auto* m : p->members) if (m->split_state != 1 || m->tdnn) return false;   // TDNN layers stay on the exact path
     return true;
 }
 
@@ -878,6 +1005,7 @@ static int ff_run_chunks(am_pipeline* p, int64_t chunk_rows, float* host_y)
         AM_TRY(e->d_overflow.ensure(16));
         HIP_TRY(hipMemsetAsync(e->d_overflow.p, 0, sizeof(int), e->stream));
     }
+    if (m0->tdnn) chunk_rows = std::min<int64_t>(chunk_rows, tdnn_chunk_frames(m0));
     for (int64_t c0 = 0; c0 < p->n; c0 += chunk_rows, ++n_chunks) {
         const int64_t nc = std::min<int64_t>(chunk_rows, p->n - c0);
         const int64_t nc_pad = round_up(nc, GEMM_BM);
@@ -890,9 +1018,11 @@ static int ff_run_chunks(am_pipeline* p, int64_t chunk_rows, float* host_y)
         if (split) {   // the frontend writes hi/lo halves directly (shared by every member)
             s.out_hi = p->d_in_s.p; s.out_lo = (_Float16*)p->d_in_s.p + (size_t)nc_pad * m0->in_pad; s.overflow = e->d_overflow.as<int>();
         }
-        AM_TRY(run_kernel(e, K_SPLICE_FT, [&] { return launch_splice_ft(e->stream, s); }));
+        if (m0->tdnn) AM_TRY(run_kernel(e, K_SPLICE_FT, [&] { return launch_splice_tdnn(e->stream, s, m0->win, m0->in_pad, nc_pad); }));
+        else AM_TRY(run_kernel(e, K_SPLICE_FT, [&] { return launch_splice_ft(e->stream, s); }));
         for (int mi = 0; mi < (int)p->members.size(); ++mi) {
-            if (split) AM_TRY(ff_member_forward_split(p, mi, nc_pad, p->d_acc.as<float>()));
+            if (m0->tdnn) AM_TRY(tdnn_member_forward(p, mi, nc_pad, p->d_acc.as<float>()));
+            else if (split) AM_TRY(ff_member_forward_split(p, mi, nc_pad, p->d_acc.as<float>()));
             else AM_TRY(ff_member_forward(p, mi, nc_pad, p->d_acc.as<float>()));
             if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(member_finish(p, mi, nc));
         }

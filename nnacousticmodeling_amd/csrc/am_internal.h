@@ -39,6 +39,7 @@ struct GemmArgs {
     int M_pad, N_pad, K_pad;      // multiples of GEMM_BM / (256 or 384) / GEMM_BK
     int act;                      // AM_ACT_* (EPI_ACT only)
     int epi; float alpha;
+    int row_p = 0, row_skip = 0;  // TDNN: output row R reads A row R + (R / row_p) * row_skip (0 = plain GEMM)
 };
 hipError_t init_kernels();  // once per device after hipSetDevice
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
@@ -67,6 +68,8 @@ struct SpliceArgs {
     void* out_hi; void* out_lo; int* overflow;        // split-f16 mode: write hi/lo halves instead of `out`
 };
 hipError_t launch_splice_ft(hipStream_t s, const SpliceArgs& a);
+// TDNN: channel-last [n_rows * W, Cp] layout of the spliced window (see splice_tdnn_kernel); rows >= a.n are zero
+hipError_t launch_splice_tdnn(hipStream_t s, const SpliceArgs& a, int W, int Cp, long long n_rows);
 
 struct FinishArgs {
     const float* in; int ldin;      // [n, ldin]

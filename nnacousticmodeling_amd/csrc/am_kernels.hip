@@ -74,7 +74,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NI], const
 template <int BN, int BK>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ bias,
-    float* __restrict__ C, int ldc, int tiles_n, int nk, int act, int epi, float alpha)
+    float* __restrict__ C, int ldc, int tiles_n, int nk, int act, int epi, float alpha, int row_p, int row_skip)
 {
     constexpr int BM = GEMM_BM, NW = GEMM_WM * GEMM_WN;
     constexpr int MI = BM / GEMM_WM / 32, NI = BN / GEMM_WN / 32;
@@ -108,7 +108,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(
     for (int j = 0; j < A_PER_WAVE; ++j) {
         const int r = (j * NW + wave) * RPI + lane / CH;
         const int c = (lane % CH) ^ ((r >> SW_SHIFT) & SW_MASK);
-        ga[j] = A + (size_t)(m0 + r) * lda + c * 4;
+        // TDNN layers (row_p > 0): output row R = (frame, position) reads the window starting at input row
+        // R + (R / row_p) * row_skip of the channel-last activation: the K extent spans the kernel's taps, no im2col copy
+        const int R = m0 + r;
+        const size_t src = row_p > 0 ? (size_t)R + (size_t)(R / row_p) * row_skip : (size_t)R;
+        ga[j] = A + src * lda + c * 4;
     }
 #pragma unroll
     for (int j = 0; j < W_PER_WAVE; ++j) {
@@ -221,11 +225,11 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g)
     if (g.N_pad % 256 == 0) {
         const int tiles_n = g.N_pad / 256;
         hipLaunchKernelGGL((gemm_nt_f32_kernel<256, 32>), dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), GEMM_LDS_256, s,
-                           g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 32, g.act, g.epi, g.alpha);
+                           g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 32, g.act, g.epi, g.alpha, g.row_p, g.row_skip);
     } else if (g.N_pad % 384 == 0) {
         const int tiles_n = g.N_pad / 384;
         hipLaunchKernelGGL((gemm_nt_f32_kernel<384, 16>), dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), GEMM_LDS_384, s,
-                           g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 16, g.act, g.epi, g.alpha);
+                           g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 16, g.act, g.epi, g.alpha, g.row_p, g.row_skip);
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -655,6 +659,46 @@ hipError_t launch_gather_ft(hipStream_t s, const GatherArgs& a)
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(gather_ft_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.x, a.ivec, a.src, (long long)a.n, (long long)a.n_pad,
                        a.D, a.add, a.scale, a.d_iv, a.out, a.ldo);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// TDNN frontend.  The reference splices +-s frames, applies the (tiled centre-frame) transform and then VIEWS each row
+// of W*D values as [C = D channels][W positions] (chainer_networks.py:39: F.reshape(x, (B, -1, 1, input_win_size))), i.e.
+// channel c, position p is flat element f = c*W + p of the spliced row -- which came from frame shift f / D, dimension
+// f % D.  The convolutions run here as GEMMs over channel-last activations, so this kernel writes
+//   out[(n*W + p) * Cp + c] = (x[clamp(first + n + shift[f / D]), f % D] + add[f]) * scale[f],   f = c*W + p
+// with zero channels c >= D (Cp = D rounded up to 32) and zero rows for n >= n_real.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void splice_tdnn_kernel(
+    const float* __restrict__ x, long long ext_rows, long long first, long long n_real, long long n_rows, int D, int W,
+    const int* __restrict__ shifts, const float* __restrict__ add, const float* __restrict__ scale, float* __restrict__ out, int Cp)
+{
+    const long long total = n_rows * W * Cp;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % Cp);
+        const long long np = idx / Cp;
+        const int p = (int)(np % W);
+        const long long n = np / W;
+        float v = 0.0f;
+        if (c < D && n < n_real) {
+            const int f = c * W + p;
+            long long r = first + n + shifts[f / D];
+            r = r < 0 ? 0 : (r >= ext_rows ? ext_rows - 1 : r);
+            v = x[r * D + f % D];
+            if (add) { const float s1 = v + add[f]; v = s1 * scale[f]; }
+        }
+        out[idx] = v;
+    }
+}
+
+hipError_t launch_splice_tdnn(hipStream_t s, const SpliceArgs& a, int W, int Cp, long long n_rows)
+{
+    if (n_rows <= 0) return hipSuccess;
+    long long blocks = (n_rows * W * Cp + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(splice_tdnn_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.x, (long long)a.ext_rows, (long long)a.first,
+                       (long long)a.n, n_rows, a.D, W, a.shifts, a.add, a.scale, a.out, Cp);
     return hipGetLastError();
 }
 

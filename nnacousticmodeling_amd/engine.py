@@ -166,6 +166,9 @@ class Model:
         elif network in RNN_CELLS:
             self._create_rnn(engine, network, params)
             return
+        elif network == "tdnn":
+            self._create_tdnn(engine, params, ACTIVATIONS[activation])
+            return
         else:
             raise ValueError("network %r is not supported by the MI355X engine (supported: ff, lstm, %s)" % (network, ", ".join(RNN_CELLS)))
         ws.append(_f32(params["out/W"]))
@@ -183,6 +186,34 @@ class Model:
         self.in_dim = int(ws[0].shape[1])
         self.num_classes = int(ws[-1].shape[0])
         self.recurrent = network == "lstm"
+
+    def _create_tdnn(self, engine, params, act):
+        """tdnn: layer_{l}/W [units_l, in_channels_l, 1, k_l] (L.Convolution2D), layer_{l}/b, out/W, out/b (am_model_create_tdnn)."""
+        ws = [_f32(params["layer_%d/W" % l]) for l in range(self.layers)]
+        bs = [_f32(params["layer_%d/b" % l]) for l in range(self.layers)]
+        out_w, out_b = _f32(params["out/W"]), _f32(params["out/b"])
+        if self.layers < 1:
+            raise ValueError("a TDNN needs at least one convolution layer")
+        cin = ws[0].shape[1] if ws[0].ndim == 4 else -1
+        for l, (w, b) in enumerate(zip(ws, bs)):   # the C side trusts these shapes
+            if w.ndim != 4 or w.shape[1] != cin or w.shape[2] != 1 or b.shape != (w.shape[0],):
+                raise ValueError("layer_%d/W has shape %s / b %s: not a (1,k) convolution over %d channels" % (l, w.shape, b.shape, cin))
+            cin = w.shape[0]
+        if out_w.shape[1:] != (cin,) or out_b.shape != (out_w.shape[0],):
+            raise ValueError("out/W has shape %s, expected (C, %d): the last convolution must leave one position" % (out_w.shape, cin))
+        n = self.layers
+        units = (C.c_int * n)(*[w.shape[0] for w in ws])
+        ksize = (C.c_int * n)(*[w.shape[3] for w in ws])
+        w_arr = (c_float_p * n)(*[_fp(w) for w in ws])
+        b_arr = (c_float_p * n)(*[_fp(b) for b in bs])
+        h = C.c_void_p()
+        check(self._lib.am_model_create_tdnn(engine._h, n, act, int(ws[0].shape[1]), units, ksize, w_arr, b_arr, _fp(out_w), _fp(out_b),
+                                             int(out_w.shape[0]), C.byref(h)))
+        self._h = h
+        self.win = sum(int(w.shape[3]) for w in ws) - n + 1
+        self.in_dim = int(ws[0].shape[1]) * self.win
+        self.num_classes = int(out_w.shape[0])
+        self.recurrent = False
 
     def _create_rnn(self, engine, network, params):
         """gru / mgrurelu / mgrurelur / peepholelstm (am_model_create_rnn; parameter order: networks.RNN_CELLS)."""

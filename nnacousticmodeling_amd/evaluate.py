@@ -17,7 +17,7 @@ import numpy as np
 
 from . import chainer_npz
 from .evaluate_model_for_test import evaluateModelTestTri
-from .kaldi_ft import loadKaldiFeatureTransform, select_centre_frame
+from .kaldi_ft import loadKaldiFeatureTransform, select_centre_frame, tdnn_splice, tile_centre_frame
 from .networks import NNWithRPL, RPL4Spec, get_nn, is_nn_recurrent  # noqa: F401  (NNWithRPL re-exported like the reference module)
 from .sharding import parse_devices, set_default_precision
 
@@ -29,7 +29,7 @@ def build_parser():
     parser.add_argument("--units", "-u", type=int, nargs="+", default=[1024], help="Number of units")
     parser.add_argument("--layers", "-l", type=int, default=2, help="Number of hidden layers")
     parser.add_argument("--activation", "-a", default="relu", help="FF activation function (sigmoid, tanh or relu)")
-    parser.add_argument("--tdnn-ksize", type=int, nargs="+", default=[5], help="TDNN kernel size (unsupported network)")
+    parser.add_argument("--tdnn-ksize", type=int, nargs="+", default=[5], help="TDNN kernel size")
     parser.add_argument("--timedelay", type=int, default=0, help="parsed and unused, exactly as in the reference (SURVEY.md M6)")
     parser.add_argument("--splice", type=int, default=0, help="Splicing size")
     parser.add_argument("--dropout", "-d", type=float, nargs="+", default=[0], help="accepted for compatibility; identity at inference")
@@ -110,6 +110,8 @@ def main(arg_list=None):
         ft = loadKaldiFeatureTransform(str(Path(args.data_dir, args.ft)))
         if recurrent:
             select_centre_frame(ft)
+        elif args.network == "tdnn":
+            tile_centre_frame(ft, tdnn_splice(args.tdnn_ksize))   # evaluate.py:152-159
 
     data = np.load(str(Path(args.data_dir, args.data.format(args.test_or_dev))))
     offsets = np.load(str(Path(args.offset_dir, args.offsets.format(args.test_or_dev))))
@@ -117,7 +119,8 @@ def main(arg_list=None):
     if args.ivector_dir is not None:
         ivectors = np.load(str(Path(args.ivector_dir, args.ivectors.format(args.test_or_dev))))
     # evaluate.py:164-171 order: splice over the whole file -> transform -> THEN append i-vectors; done on the GPU
-    shifts = list(range(-args.splice, args.splice + 1)) if args.splice > 0 else [0]
+    splice = tdnn_splice(args.tdnn_ksize) if args.network == "tdnn" else args.splice   # evaluate.py:138-141
+    shifts = list(range(-splice, splice + 1)) if splice > 0 else [0]
 
     if not args.tri:
         print("Monophones not implemented")

@@ -34,3 +34,21 @@ def select_centre_frame(ft):
     ft["shape"][0] = dim
     ft["shifts"] = [0]
     return ft
+
+
+def tile_centre_frame(ft, splice):
+    """In place, as the reference does for ``tdnn`` (evaluate.py:152-159, predict_folds.py:179-186): the un-shifted
+    frame's transform repeated over the 2*splice+1 frames of the network's own window."""
+    dim = ft["shape"][1]
+    zi = ft["shifts"].index(0)
+    winlen = 2 * splice + 1
+    ft["rescale"] = np.tile(ft["rescale"][zi * dim:(zi + 1) * dim], winlen)
+    ft["addShift"] = np.tile(ft["addShift"][zi * dim:(zi + 1) * dim], winlen)
+    ft["shape"][0] = dim * winlen
+    ft["shifts"] = list(range(-splice, splice + 1))
+    return ft
+
+
+def tdnn_splice(ksize):
+    """Frames of context a TDNN needs on each side: (sum(ksize) - len(ksize)) // 2 (evaluate.py:138-139)."""
+    return (sum(ksize) - len(ksize)) // 2

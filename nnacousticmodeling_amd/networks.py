@@ -1,4 +1,4 @@
-"""Host-side network descriptions mirroring the reference's model zoo (every get_nn network except tdnn).
+"""Host-side network descriptions mirroring the reference's model zoo (every get_nn network).
 
 ``get_nn`` / ``is_nn_recurrent`` follow scripts/common/chainer_networks.py:163-187; ``NNWithRPL`` follows
 scripts/common/evaluate.py:19-51; ``RPL4`` follows scripts/common/RPL.py:58-74.  The objects here hold host copies of
@@ -10,7 +10,7 @@ import numpy as np
 
 from ._lib import AM_CELL_GRU, AM_CELL_MGRU, AM_CELL_PEEPHOLE
 
-SUPPORTED = ("ff", "lstm", "zoneoutlstm", "zoneoutdropoutlstm", "gru", "mgrurelu", "mgrurelur", "peepholelstm")
+SUPPORTED = ("ff", "tdnn", "lstm", "zoneoutlstm", "zoneoutdropoutlstm", "gru", "mgrurelu", "mgrurelur", "peepholelstm")
 # At inference (chainer.config.train = False) zoneout returns the new state, so L.StatefulZoneoutLSTM computes exactly
 # what L.LSTM computes (upward Linear + bias-free lateral Linear, interleaved gates, h = None -> zeros on the first step)
 # and its npz keys are the same; both zoneout variants of the reference (chainer_networks.py:64-101) therefore run on the
@@ -36,10 +36,17 @@ def is_nn_recurrent(n):
 class NetworkSpec:
     """An un-initialised network, as ``get_nn`` returns it; ``chainer_npz.load_npz`` fills the parameters."""
 
-    def __init__(self, network, layers, units, num_classes, activation="relu"):
+    def __init__(self, network, layers, units, num_classes, activation="relu", tdnn_ksize=None):
         self.reference_network = network                                   # the name given on the command line
         network = "lstm" if network in LSTM_EQUIVALENT else network        # the device path that runs it
         self.network = network
+        if network == "tdnn":   # TDNN(units, num_classes, tdnn_ksize, ...): one conv layer per entry, --layers is ignored (chainer_networks.py:24-36)
+            self.units_list = [int(u) for u in units]
+            self.ksize = [int(k) for k in tdnn_ksize]
+            if len(self.units_list) != len(self.ksize):
+                raise ValueError("TDNN n_units argument must have the same length as ksize")
+            layers, units = len(self.units_list), self.units_list[-1]
+            self.input_win_size = sum(self.ksize) - len(self.ksize) + 1
         self.layers = int(layers)
         self.units = int(units)
         self.num_classes = int(num_classes)
@@ -57,7 +64,7 @@ class NetworkSpec:
     def expected_keys(self):
         keys = []
         for l in range(self.layers):
-            if self.network == "ff":
+            if self.network in ("ff", "tdnn"):
                 keys += ["layer_%d/W" % l, "layer_%d/b" % l]
             elif self.network in RNN_CELLS:
                 keys += ["layer_%d/%s" % (l, k) for k in RNN_CELLS[self.network][2]]
@@ -73,6 +80,12 @@ class NetworkSpec:
             raise KeyError("%s: missing parameter(s) %s for a %d-layer %s network" % (source, missing, self.layers, self.network))
         p = {k: np.ascontiguousarray(params[k], dtype=np.float32) for k in self.expected_keys()}
         for l in range(self.layers):
+            if self.network == "tdnn":   # L.Convolution2D(None, units, ksize=(1, k)): W [units, in_channels, 1, k]
+                w, b = p["layer_%d/W" % l], p["layer_%d/b" % l]
+                cin = self.units_list[l - 1] if l > 0 else (w.shape[1] if w.ndim == 4 else -1)
+                if w.shape != (self.units_list[l], cin, 1, self.ksize[l]) or b.shape != (self.units_list[l],):
+                    raise ValueError("%s: layer_%d/W has shape %s, expected %s" % (source, l, w.shape, (self.units_list[l], cin, 1, self.ksize[l])))
+                continue
             if self.network in RNN_CELLS and self.network != "peepholelstm":
                 # every Linear of a GRU / MGRU link has `units` outputs; the state Linears are units x units
                 for k in RNN_CELLS[self.network][2]:
@@ -104,9 +117,11 @@ class NetworkSpec:
 
     @property
     def in_dim(self):
-        key = "layer_0/W" if self.network == "ff" else "layer_0/W_z/W" if self.network in RNN_CELLS and self.network != "peepholelstm" else "layer_0/upward/W"
+        key = "layer_0/W" if self.network in ("ff", "tdnn") else "layer_0/W_z/W" if self.network in RNN_CELLS and self.network != "peepholelstm" else "layer_0/upward/W"
         if self.layers == 0:
             key = "out/W"
+        if self.network == "tdnn":
+            return int(self.params[key].shape[1]) * self.input_win_size
         return int(self.params[key].shape[1])
 
 
@@ -136,6 +151,8 @@ def get_nn(network, layers, units, num_classes, activation="relu", tdnn_ksize=No
     if network in SUPPORTED:
         if activation not in ("relu", "sigmoid", "tanh"):
             raise ValueError("Wrong activation function specified")
+        if network == "tdnn":
+            return NetworkSpec(network, layers, list(units), num_classes, activation, list(tdnn_ksize))
         return NetworkSpec(network, layers, units[0] if isinstance(units, (list, tuple)) else units, num_classes, activation)
     if network in ALL_REFERENCE_NETWORKS:
         raise NotImplementedError("network %r exists in the reference but is not built here yet (supported: %s)" % (network, ", ".join(SUPPORTED)))

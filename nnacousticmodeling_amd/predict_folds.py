@@ -17,7 +17,7 @@ import numpy as np
 
 from . import chainer_npz
 from ._lib import AM_COMBINE_LOGITS, AM_COMBINE_LOGPOST
-from .kaldi_ft import loadKaldiFeatureTransform, select_centre_frame
+from .kaldi_ft import loadKaldiFeatureTransform, select_centre_frame, tdnn_splice, tile_centre_frame
 from .networks import get_nn, is_nn_recurrent
 from .sharding import get_runner, parse_devices, set_default_precision
 
@@ -48,7 +48,7 @@ def build_parser():
     parser.add_argument("--units", "-u", type=int, nargs="+", default=[1024], help="Number of units")
     parser.add_argument("--layers", "-l", type=int, default=2, help="Number of hidden layers")
     parser.add_argument("--activation", "-a", default="relu", help="FF activation function (sigmoid, tanh or relu)")
-    parser.add_argument("--tdnn-ksize", type=int, nargs="+", default=[5], help="TDNN kernel size (unsupported network)")
+    parser.add_argument("--tdnn-ksize", type=int, nargs="+", default=[5], help="TDNN kernel size")
     parser.add_argument("--timedelay", type=int, default=0, help="Delay target values by this many time steps")
     parser.add_argument("--splice", type=int, default=0, help="Splicing size")
     parser.add_argument("--dropout", "-d", type=float, nargs="+", default=[0], help="accepted for compatibility; identity at inference")
@@ -76,12 +76,14 @@ def build_parser():
 
 
 def load_feature_transform(args, recurrent):
-    """predict_folds.py:170-188 (the tdnn branch is out of scope)."""
+    """predict_folds.py:170-188: recurrent nets keep the centre frame's transform, tdnn tiles it over its own window."""
     if args.ft is None or args.ft == "-":
         return None
     ft = loadKaldiFeatureTransform(str(Path(args.data_dir, args.ft)))
     if recurrent:
         select_centre_frame(ft)
+    elif args.network == "tdnn":
+        tile_centre_frame(ft, tdnn_splice(args.tdnn_ksize))
     return ft
 
 
@@ -105,13 +107,11 @@ def main(arg_list=None):
     if args.activation not in ("sigmoid", "tanh", "relu"):
         print("Wrong activation function specified")
         sys.exit(1)
-    if args.network == "tdnn":
-        print("Wrong network type specified")  # outside the hot-path scope
-        sys.exit(1)
     devices = parse_devices(args.gpu, args.gpus)
     set_default_precision(args.precision)
     recurrent = is_nn_recurrent(args.network)
-    winlen = 2 * args.splice + 1
+    splice = tdnn_splice(args.tdnn_ksize) if args.network == "tdnn" else args.splice   # predict_folds.py:163-167
+    winlen = 2 * splice + 1
     ft = load_feature_transform(args, recurrent)
 
     def fold_models():

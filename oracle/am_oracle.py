@@ -65,6 +65,21 @@ def centre_frame_transform(ft):
     }
 
 
+def tdnn_frame_transform(ft, ksize):
+    """TDNN: the centre frame's transform tiled over the network's own window of 2*splice+1 frames,
+    splice = (sum(ksize) - len(ksize)) // 2 (evaluate.py:138-139,152-159)."""
+    dim = ft["shape"][1]
+    zi = ft["shifts"].index(0)
+    splice_ctx = (sum(ksize) - len(ksize)) // 2
+    winlen = 2 * splice_ctx + 1
+    return {
+        "shape": [dim * winlen, dim],
+        "shifts": list(range(-splice_ctx, splice_ctx + 1)),
+        "addShift": np.tile(ft["addShift"][zi * dim:(zi + 1) * dim], winlen),
+        "rescale": np.tile(ft["rescale"][zi * dim:(zi + 1) * dim], winlen),
+    }
+
+
 def apply_feature_transform(x, ft):
     """``(x + addShift) * rescale`` -- add first, then multiply (kw_nn_utils.py:13-17)."""
     x1 = x + ft["addShift"]
@@ -247,6 +262,36 @@ class LSTM:
         return _linear(x, self.w_out, self.b_out)
 
 
+class TDNN:
+    """``TDNN`` (chainer_networks.py:24-42): ``x.reshape(B, -1, 1, W)`` with ``W = sum(ksize) - len(ksize) + 1``, then
+    ``L.Convolution2D(None, units, ksize=(1, k), stride=1)`` + activation per layer (cross-correlation, no padding), then
+    ``out`` on the flattened map.  The reshape makes channel c, position p the element ``c*W + p`` of the spliced row.
+    Chainer semantics, parity unpinned."""
+
+    recurrent = False
+
+    def __init__(self, params, layers, activation="relu", dtype=np.float32):
+        self.dtype = dtype
+        self.w = [np.asarray(params["layer_%d/W" % l], dtype=dtype) for l in range(layers)]
+        self.b = [np.asarray(params["layer_%d/b" % l], dtype=dtype) for l in range(layers)]
+        self.w_out = np.asarray(params["out/W"], dtype=dtype)
+        self.b_out = np.asarray(params["out/b"], dtype=dtype)
+        self.act = _activation(activation)
+        self.input_win_size = sum(w.shape[3] for w in self.w) - layers + 1
+
+    def reset_state(self):
+        pass
+
+    def __call__(self, x):
+        x = np.asarray(x, dtype=self.dtype)
+        h = x.reshape(x.shape[0], -1, self.input_win_size)                       # [B, C, W] (the height-1 axis dropped)
+        for w, b in zip(self.w, self.b):
+            k = w.shape[3]
+            win = np.lib.stride_tricks.sliding_window_view(h, k, axis=2)          # [B, C, P, k]
+            h = self.act(np.einsum("bcpj,ucj->bup", win, w[:, :, 0, :], optimize=True).astype(self.dtype) + b[None, :, None])
+        return _linear(h.reshape(h.shape[0], -1), self.w_out, self.b_out)
+
+
 class MGRUNet:
     """Stack of stateful MGRU links + ``out`` (``NetMGRU``, chainer_networks.py:143-161; cell: MGRU.py:35-85), and --
     with ``use_reset_gate=True, activation="tanh"`` -- chainer's ``L.GRU`` stack (``GRU``, chainer_networks.py:123-141):
@@ -398,6 +443,8 @@ def get_nn(network, layers, params, activation="relu", dtype=np.float32):
     """``get_nn`` restricted to the in-scope networks (chainer_networks.py:163-184)."""
     if network == "ff":
         return MLP(params, layers, activation, dtype)
+    if network == "tdnn":
+        return TDNN(params, layers, activation, dtype)
     if network in ("lstm", "zoneoutlstm", "zoneoutdropoutlstm"):   # zoneout is the identity at inference
         return LSTM(params, layers, dtype)
     if network == "gru":
@@ -566,6 +613,19 @@ def make_lstm_params(rng, in_dim, units, layers, n_out, bias_scale=0.1):
         p["layer_%d/lateral/W" % l] = (rng.standard_normal((4 * units, units)) / np.sqrt(units)).astype(np.float32)
         d = units
     p["out/W"] = (rng.standard_normal((n_out, d)) / np.sqrt(d)).astype(np.float32)
+    p["out/b"] = (bias_scale * rng.standard_normal(n_out)).astype(np.float32)
+    return p
+
+
+def make_tdnn_params(rng, in_channels, units, ksize, n_out, bias_scale=0.1):
+    """Synthetic parameters of a TDNN in Chainer's layout: layer_{l}/W [units_l, in_l, 1, k_l], layer_{l}/b."""
+    p = {}
+    c = in_channels
+    for l, (u, k) in enumerate(zip(units, ksize)):
+        p["layer_%d/W" % l] = (rng.standard_normal((u, c, 1, k)) / np.sqrt(c * k)).astype(np.float32)
+        p["layer_%d/b" % l] = (bias_scale * rng.standard_normal(u)).astype(np.float32)
+        c = u
+    p["out/W"] = (rng.standard_normal((n_out, c)) / np.sqrt(c)).astype(np.float32)
     p["out/b"] = (bias_scale * rng.standard_normal(n_out)).astype(np.float32)
     return p
 

@@ -68,8 +68,10 @@ def test_chainer_npz_roundtrip_and_shape_checks(tmp_path):
 def test_get_nn_scope():
     assert networks.is_nn_recurrent("lstm") and networks.is_nn_recurrent("zoneoutlstm") and networks.is_nn_recurrent("gru")
     assert networks.is_nn_recurrent("mgrurelu") and not networks.is_nn_recurrent("ff") and not networks.is_nn_recurrent("tdnn")
-    with pytest.raises(NotImplementedError):
-        networks.get_nn("tdnn", 2, [64, 64], 1909, "relu", [5, 5])
+    t = networks.get_nn("tdnn", 7, [64, 32], 1909, "relu", [5, 3])   # --layers is ignored: one conv layer per --units entry
+    assert t.layers == 2 and t.input_win_size == 7 and not t.recurrent
+    with pytest.raises(ValueError):
+        networks.get_nn("tdnn", 2, [64, 64], 1909, "relu", [5])
     for name, n_keys in (("gru", 12), ("mgrurelur", 12), ("mgrurelu", 8), ("peepholelstm", 6)):
         spec = networks.get_nn(name, 2, [64], 1909, "sigmoid")   # the cells' own activations are hard-wired (chainer_networks.py:174-181)
         assert spec.network == name and spec.recurrent and len(spec.expected_keys()) == 2 * n_keys + 2

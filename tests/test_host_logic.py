@@ -159,6 +159,26 @@ def test_predict_folds_cli_recurrent_timedelay(tmp_path, fake_runners, real_ft_p
     assert got.shape == (60, 39) and np.max(np.abs(got - want)) < 1e-5
 
 
+def test_predict_folds_cli_tdnn(tmp_path, fake_runners, real_ft_path):
+    """-n tdnn: the splice comes from --tdnn-ksize (not --splice), the transform is the centre frame tiled over the
+    network's window (predict_folds.py:163-186), --layers is ignored (one conv layer per --units entry)."""
+    rng = np.random.default_rng(8)
+    data_dir, model_dir, out_dir = (tmp_path / d for d in ("data", "models", "out"))
+    data_dir.mkdir(), model_dir.mkdir()
+    _write_ft(data_dir / "final.feature_transform", real_ft_path)
+    ksize, units = [3, 5], [12, 10]
+    ft = orc.tdnn_frame_transform(orc.load_kaldi_feature_transform(real_ft_path), ksize)
+    params = orc.make_tdnn_params(rng, 40, units, ksize, 39)
+    chainer_npz.write_npz(model_dir / "fold_0.npz", params)
+    x = rng.standard_normal((50, 40)).astype(np.float32)
+    np.save(data_dir / "data_0.npy", x)
+    predict_folds.main(["-n", "tdnn", "-l", 9, "-u", *units, "--tdnn-ksize", *ksize, "--splice", 1, "-a", "tanh", "--ft", "final.feature_transform",
+                        "--data-dir", data_dir, "--fold-data-dir", data_dir, "--fold-model-dir", model_dir, "--fold-output-dir", out_dir, "--no-progress"])
+    got = np.load(out_dir / "data_0.npy")
+    want = orc.predict(orc.TDNN(params, 2, "tanh"), x, None, False, 7, 0, ft)
+    assert got.shape == (50, 39) and np.max(np.abs(got - want)) < 1e-5
+
+
 def _eval_dirs(tmp_path, real_ft_path, real_priors, n_utts, n_frames, rng):
     data_dir, recog_dir, lab_dir = tmp_path / "data", tmp_path / "recog", tmp_path / "lab"
     data_dir.mkdir(), recog_dir.mkdir()

@@ -106,6 +106,26 @@ def main():
             fl = 2 * (40 * 2048 + 2 * 512 * 2048 + 3 * 512 * 2048 + 512 * 1909)
             report("3x512 LSTM N=57919 192 utts Tmax=%d timedelay=%d" % (int(np.diff(offsets).max()), td), N, wall, ms, calls, fl)
             p.close()
+    if args.which in ("all", "tdnn"):
+        # tsd2018's TDNN sweeps (scripts/papers/tsd2018/run.sh:22-30): 5-5-5-5 and 9-9-9-9 kernels, 1024 units
+        for ksize in ([5, 5, 5, 5], [9, 9, 9, 9]):
+            units = [1024] * 4
+            params = orc.make_tdnn_params(rng, 40, units, ksize, 1909)
+            tft = orc.tdnn_frame_transform(ft, ksize)
+            m = Model(eng, "tdnn", 4, params)
+            p = Pipeline(eng)
+            p.set_frontend(40, tft["shifts"], tft["addShift"], tft["rescale"])
+            p.set_members([m])
+            p.ff_upload(x)
+            wall, ms, calls = timed(eng, p.ff_run, args.steps, 1)
+            pos, cin, fl = sum(ksize) - 3, 40, 0
+            for u, k in zip(units, ksize):
+                pos -= k - 1
+                fl += 2 * pos * cin * k * u
+                cin = u
+            fl += 2 * cin * 1909
+            report("tdnn %s x1024 N=57919" % "-".join(map(str, ksize)), N, wall, ms, calls, fl)
+            p.close()
     if args.which in ("all", "cells"):
         # the other recurrent cells of get_nn at the LSTM config's size
         for net in ("gru", "mgrurelu", "peepholelstm"):
