@@ -4,6 +4,7 @@
 whose keys are link paths joined by ``/`` under the ``predictor/`` prefix:
   ff   : predictor/layer_{l}/W [units,in], predictor/layer_{l}/b [units], predictor/out/W [C,units], predictor/out/b [C]
   lstm : predictor/layer_{l}/upward/W [4U,in], predictor/layer_{l}/upward/b [4U], predictor/layer_{l}/lateral/W [4U,U]
+  tdnn : predictor/layer_{l}/W [units_l, in_channels_l, 1, k_l] (L.Convolution2D), predictor/layer_{l}/b, out/W [C, units_last]
   gru / mgrurelu[r] : predictor/layer_{l}/{W_r,U_r,W_z,U_z,W,U}/{W,b}  (MGRU.py:10-32; no W_r/U_r without reset gate)
   peepholelstm : the lstm keys + predictor/layer_{l}/{peep_i,peep_f,peep_o}/W [U,U]
   RPL4 : predictor/W, predictor/b, predictor/lb  each [1,C]

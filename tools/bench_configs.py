@@ -116,7 +116,7 @@ def main():
             p = Pipeline(eng)
             p.set_frontend(40, tft["shifts"], tft["addShift"], tft["rescale"])
             p.set_members([m])
-            p.ff_upload(x)
+            p.ff_upload(x, None, N, 0, 0)
             wall, ms, calls = timed(eng, p.ff_run, args.steps, 1)
             pos, cin, fl = sum(ksize) - 3, 40, 0
             for u, k in zip(units, ksize):
