@@ -202,7 +202,7 @@ def test_api_errors(engine):
     with pytest.raises(AmError):  # frontend width 440 != network input 100
         p.forward_ff(np.zeros((10, 40), dtype=np.float32))
     with pytest.raises(ValueError):
-        _mk(engine, "gru", 1, {})
+        _mk(engine, "transformer", 1, {})   # not one of the reference's get_nn networks
 
 
 def test_lstm_ensembles_ivectors_and_dev_average(engine, real_ft_path, real_priors):
