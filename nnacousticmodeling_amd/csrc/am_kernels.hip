@@ -864,6 +864,167 @@ __global__ __launch_bounds__(512, 4) void lstm_wavefront_kernel(const LstmWavefr
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The same step with a DEEP register prefetch of the weights ("wreg"): used when every layer's K is a multiple of 512
+// (4 batches of 128 k; 3x512: 512 for the hoisted layer, 1024 for the others).
+// The streaming kernel above prefetches one 128-k batch ahead, and every batch costs a full memory round trip
+// (~1.6-2 us: the weight set is re-fetched from beyond L2 every launch) against 0.2-0.9 us of MFMA work per block.
+// Here a wave keeps the weight fragments of FOUR batches in flight (4 x 4 x 16 B per lane = 64 VGPRs), refilled one batch
+// per iteration, and the shared activation rows two batches ahead through a double-buffered LDS tile (one barrier per
+// batch); loads are issued in consumption order (A0 W0 A1 W1 W2 W3 | A2 W4 | A3 W5 ...) because a wave's loads return
+// in order: with all weights issued up front, the activation tile of batch 2 queued behind the whole weight stream
+// (measured: 30 us per launch at 192 rows, fully additive: 13 us A path + 9 us weight stream + 9 us MFMA).
+// One block per CU (registers), 1..6 row tiles per block (at 6 the weight window is 2 batches).  Same summation order as the other two kernels.
+// ---------------------------------------------------------------------------------------------------
+constexpr int LSTM_WREG_ROWS = 96;        // row capacity of the LDS tiles (6 row tiles)
+constexpr size_t LSTM_WREG_LDS = 2 * LSTM_WREG_ROWS * LSTM_LDA * sizeof(float);   // 101,376 B; the gate exchange buffer aliases it after the K loop
+
+template <int NT>
+__device__ __forceinline__ void lstm_wreg_body(const LstmLayerStep& Ls, int U_pad, int ut, int row0, float* smem)
+{
+    constexpr int ROWS = NT * 16;
+    constexpr int EP = (ROWS * 16 + 511) / 512;       // epilogue items per thread
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gate = wave & 3, kh = wave >> 2;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int ldg = 4 * U_pad;
+    const int first = Ls.first, n_active = Ls.n_active;
+    float* sA0 = smem;
+    float* sA1 = smem + LSTM_WREG_ROWS * LSTM_LDA;
+
+    float gpre[EP][4], cprev[EP];
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+        const int idx = tid + 512 * e, erow = idx >> 4, eu = idx & 15, slot = row0 + erow;
+        const bool live = erow < ROWS && slot < n_active;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            gpre[e][k] = !live ? 0.0f : (Ls.G ? Ls.G[(size_t)slot * ldg + ut * 64 + k * 16 + eu] : Ls.bias[ut * 64 + k * 16 + eu]);
+        cprev[e] = (!first && live) ? Ls.Cst[(size_t)slot * U_pad + ut * 16 + eu] : 0.0f;
+    }
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int r = 0; r < NT; ++r) acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const int nb0 = Ls.Hin ? Ls.Kin_pad / LSTM_KB : 0;     // batches of the upward segment, the rest is lateral
+    const int nb = nb0 + (first ? 0 : U_pad / LSTM_KB);    // a multiple of 4 (launcher)
+    if (nb > 0) {
+        // A chunk e of a batch = row tile e: thread -> (row = idx / 32, 16-B column idx % 32)
+        constexpr int D = NT >= 6 ? 2 : 4;   // weight batches in flight (6 tiles: 2.6 us of MFMA per batch already covers a round trip; 4 would spill)
+        f32x4 av[2][NT], wv[D][LSTM_KS];
+        auto load_a = [&](int b, f32x4 (&dst)[NT]) {
+            b = b < nb ? b : nb - 1;       // past the end: re-fetch the last batch (never consumed), keeps the loop branch-free
+            const float* ap; int K;
+            if (b < nb0) { K = Ls.Kin_pad; ap = Ls.Hin + (size_t)row0 * K + b * LSTM_KB; }
+            else { K = U_pad; ap = Ls.Hprev + (size_t)row0 * K + (b - nb0) * LSTM_KB; }
+#pragma unroll
+            for (int e = 0; e < NT; ++e) {
+                const int idx = tid + 512 * e, r = idx / (LSTM_KB / 4), c4 = idx % (LSTM_KB / 4);
+                dst[e] = *(const f32x4*)(ap + (size_t)r * K + 4 * c4);
+            }
+        };
+        auto load_w = [&](int b, f32x4 (&dst)[LSTM_KS]) {
+            b = b < nb ? b : nb - 1;
+            const float* wp; int K;
+            if (b < nb0) { K = Ls.Kin_pad; wp = Ls.Wup + b * LSTM_KB; }
+            else { K = U_pad; wp = Ls.Wlat + (b - nb0) * LSTM_KB; }
+            wp += (size_t)(ut * 64 + gate * 16 + l15) * K + kh * (LSTM_KB / 2) + 4 * lq;
+#pragma unroll
+            for (int s = 0; s < LSTM_KS; ++s) dst[s] = *(const f32x4*)(wp + 16 * s);
+        };
+        load_a(0, av[0]); load_w(0, wv[0]);
+        load_a(1, av[1]); load_w(1, wv[1]);
+        if constexpr (D == 4) { load_w(2, wv[2]); load_w(3, wv[3]); }
+        for (int b0 = 0; b0 < nb; b0 += 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int b = b0 + i;
+                float* sA = (i & 1) ? sA1 : sA0;
+#pragma unroll
+                for (int e = 0; e < NT; ++e) {
+                    const int idx = tid + 512 * e, r = idx / (LSTM_KB / 4), c4 = idx % (LSTM_KB / 4);
+                    *(f32x4*)(sA + r * LSTM_LDA + 4 * c4) = av[i & 1][e];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();   // tile b is complete; everyone left tile b-2 (same buffer) before its barrier b-1
+                load_a(b + 2, av[i & 1]);
+                const float* sa = sA + l15 * LSTM_LDA + kh * (LSTM_KB / 2) + 4 * lq;
+                f32x4 pb[NT];
+#pragma unroll
+                for (int r = 0; r < NT; ++r) pb[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int s = 0; s < LSTM_KS; ++s) {
+                    f32x4 a[NT];
+#pragma unroll
+                    for (int r = 0; r < NT; ++r) a[r] = *(const f32x4*)(sa + r * 16 * LSTM_LDA + 16 * s);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < NT; ++r) pb[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], wv[i % D][s][j], pb[r], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < NT; ++r) acc[r] += pb[r];
+                load_w(b + D, wv[i % D]);       // refill this slot: D batches ahead
+            }
+        }
+        __syncthreads();                    // all fragment reads of the A tiles are done: reuse the space for the gate exchange
+    }
+    float* sg = smem;                       // [kh][gate][ROWS][17]
+#pragma unroll
+    for (int r = 0; r < NT; ++r)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            sg[((kh * 4 + gate) * ROWS + r * 16 + lq * 4 + reg) * 17 + l15] = acc[r][reg];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+        const int idx = tid + 512 * e, erow = idx >> 4, eu = idx & 15, slot = row0 + erow;
+        if (erow < ROWS && slot < n_active) {
+            float pre[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                pre[k] = (sg[((0 * 4 + k) * ROWS + erow) * 17 + eu] + sg[((1 * 4 + k) * ROWS + erow) * 17 + eu]) + gpre[e][k];
+            const float a = tanhf(pre[0]);
+            const float i = am_sigmoid(pre[1]);
+            const float f = am_sigmoid(pre[2]);
+            const float o = am_sigmoid(pre[3]);
+            const float ai = a * i;
+            const float fc = f * cprev[e];
+            const float c = ai + fc;
+            const size_t cidx = (size_t)slot * U_pad + ut * 16 + eu;
+            Ls.Cst[cidx] = c;
+            Ls.Hout[cidx] = o * tanhf(c);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void lstm_wreg_kernel(const LstmWavefrontArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) float wreg_smem[];
+    int li = 0;
+#pragma unroll
+    for (int l = 1; l < LSTM_MAX_LAYERS; ++l) if (l < args.n && (int)blockIdx.x >= args.L[l].block0) li = l;
+    const LstmLayerStep& Ls = args.L[li];
+    const int U_pad = args.U_pad, ut_groups = args.ut_groups;
+    const int bid = blockIdx.x - Ls.block0;
+    const int ut = (bid & 7) + 8 * ((bid >> 3) % ut_groups);
+    const int rt = (bid >> 3) / ut_groups;
+    if (ut * 16 >= U_pad) return;
+    const int row0 = rt * Ls.tpb * 16;
+    const int tiles_left = (Ls.n_active - row0 + 15) / 16;
+    const int ntile = tiles_left < Ls.tpb ? tiles_left : Ls.tpb;
+    switch (ntile) {   // uniform per block
+    case 1: lstm_wreg_body<1>(Ls, U_pad, ut, row0, wreg_smem); break;
+    case 2: lstm_wreg_body<2>(Ls, U_pad, ut, row0, wreg_smem); break;
+    case 3: lstm_wreg_body<3>(Ls, U_pad, ut, row0, wreg_smem); break;
+    case 4: lstm_wreg_body<4>(Ls, U_pad, ut, row0, wreg_smem); break;
+    case 5: lstm_wreg_body<5>(Ls, U_pad, ut, row0, wreg_smem); break;
+    case 6: lstm_wreg_body<6>(Ls, U_pad, ut, row0, wreg_smem); break;
+    default: break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // The same step for FEW active utterances (<= 16*R rows per layer; half of the launches of a TIMIT-like file run with
 // <= 16 rows).  The wide kernel above walks K in 8 serial batches, one memory round trip each (1.6 us), on only
 // 32 blocks per layer; with few rows the step is pure latency.  Here K is split over the 8 waves of a block instead and
@@ -972,8 +1133,17 @@ __global__ __launch_bounds__(512) void lstm_thin_kernel(const LstmWavefrontArgs 
 }
 
 constexpr size_t LSTM_THIN_LDS_MAX = 72 * 1024;   // two blocks per CU stay co-resident
+static int lstm_wreg_mode()
+{
+    static int mode = -1;   // AM_LSTM_WREG=0 keeps the streaming kernel (A/B measurements)
+    if (mode < 0) { const char* v = getenv("AM_LSTM_WREG"); mode = v ? atoi(v) : 1; }
+    return mode;
+}
+
 hipError_t init_lstm_kernels()
 {
+    hipError_t we = hipFuncSetAttribute((const void*)lstm_wreg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_WREG_LDS);
+    if (we != hipSuccess) return we;
     hipError_t e = hipFuncSetAttribute((const void*)lstm_thin_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_THIN_LDS_MAX);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)lstm_thin_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_THIN_LDS_MAX);
@@ -1025,6 +1195,42 @@ hipError_t launch_lstm_wavefront(hipStream_t s, LstmWavefrontArgs& a)
     for (int l = 0; l < a.n; ++l) {
         Kl[l] = (a.L[l].Hin ? a.L[l].Kin_pad : 0) + (a.L[l].first ? 0 : a.U_pad);
         Kmax = std::max(Kmax, Kl[l]);
+    }
+    // W-resident kernel: every layer's K fits 8 batches.  One block per CU, so a launch takes (rounds of 256 blocks) x
+    // (the costliest block's tile-times + ~1.5 tile-times of fixed cost: the weight round trip, the first A tile, the
+    // gate epilogue).  Layers whose K fits 4 batches may take up to 6 row tiles per block (half the weight registers).
+    bool wreg = lstm_wreg_mode() != 0;
+    for (int l = 0; l < a.n; ++l) {
+        if (Kl[l] % (4 * LSTM_KB)) wreg = false;
+    }
+    if (wreg) {
+        int best_f = 4, best_p = 4; float best = 1e30f;
+        for (int cf = 6; cf >= 1; --cf)
+            for (int cp = 6; cp >= 1; --cp) {
+                int blocks = 0; float work = 0.0f; bool any_part = false, any_full = false;
+                for (int l = 0; l < a.n; ++l) {
+                    const bool part = Kl[l] < Kmax;
+                    any_part |= part; any_full |= !part;
+                    const int cand = part ? cp : cf;
+                    blocks += lstm_blocks_for(a.L[l].n_active, a.U_pad, cand);
+                    work = std::max(work, cand * (float)Kl[l] / (8 * LSTM_KB));
+                }
+                if ((!any_part && cp != 6) || (!any_full && cf != 6)) continue;
+                const int rounds = (blocks + 255) / 256;
+                const float cost = rounds * (work + 1.5f);
+                if (cost < best - 1e-6f) { best = cost; best_f = cf; best_p = cp; }
+            }
+        int total = 0;
+        for (int l = 0; l < a.n; ++l) {
+            const int tpb = Kl[l] < Kmax ? best_p : best_f;
+            const int n_tiles = (a.L[l].n_active + 15) / 16, n_rt = (n_tiles + tpb - 1) / tpb;
+            a.L[l].tpb = n_rt > 0 ? (n_tiles + n_rt - 1) / n_rt : 1;
+            a.L[l].block0 = total;
+            total += 8 * a.ut_groups * n_rt;
+        }
+        if (total == 0) return hipSuccess;
+        hipLaunchKernelGGL(lstm_wreg_kernel, dim3(total), dim3(512), LSTM_WREG_LDS, s, a);
+        return hipGetLastError();
     }
     int tpb_full = 4, tpb_part = 4;   // layers with K == Kmax / with a shorter K
     {

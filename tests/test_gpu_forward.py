@@ -146,6 +146,28 @@ def test_lstm_evaluate_surface_a(engine, real_ft_path, real_priors):
     assert np.max(np.abs(got - want64)) <= TOL
 
 
+@pytest.mark.parametrize("units,layers", [(192, 2), (1024, 2)])
+def test_lstm_wide_kernels_other_widths(engine, real_ft_path, units, layers):
+    """> 32 active utterances at widths other than 512: U = 192 (K not a multiple of 512: the streaming step kernel) and
+    U = 1024 (K = 1024 / 2048: the deep-prefetch kernel's loop runs 2 and 4 times); plus batch-composition invariance
+    across the three step kernels (the halves finish on the few-rows kernel earlier than the whole)."""
+    rng = np.random.default_rng(units)
+    ft = orc.centre_frame_transform(_ft(real_ft_path))
+    params = orc.make_lstm_params(rng, 40, units, layers, 1909)
+    offsets = orc.make_offsets(rng, 56, 2400, lo=8, hi=90)
+    x = rng.standard_normal((2400, 40)).astype(np.float32)
+    want = orc.predict(orc.LSTM(params, layers), x, offsets, True, 1, 0, ft)
+    p = _pipe(engine)
+    p.set_frontend(40, [0], ft["addShift"], ft["rescale"])
+    p.set_members([_mk(engine, "lstm", layers, params)])
+    got = p.forward_lstm(x, offsets)
+    assert np.max(np.abs(got - want)) <= TOL
+    cut = 20
+    a = p.forward_lstm(x[:offsets[cut]], offsets[:cut + 1])
+    b = p.forward_lstm(x[offsets[cut]:], offsets[cut:] - offsets[cut])
+    assert np.array_equal(np.concatenate([a, b]), got)
+
+
 def test_ensemble_logit_average_and_rpl4(engine, real_ft_path, real_priors):
     """NNWithRPL (evaluate.py:35-51): (K*master + sum folds)/(2K), folds only, and the RPL4 epilogue (RPL.py:68-74)."""
     rng = np.random.default_rng(51)

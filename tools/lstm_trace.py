@@ -18,7 +18,7 @@ def main():
     # passes: maximal runs of lstm_wavefront launches
     runs, cur = [], []
     for i, r in enumerate(rows):
-        if "lstm_wavefront" in r[2]:
+        if "lstm_w" in r[2] or "lstm_thin" in r[2] or "rec_step" in r[2]:
             cur.append(i)
         elif cur:
             runs.append(cur)
@@ -41,7 +41,7 @@ def main():
     lo, hi = rows[run[0]][0] - 3_000_000, rows[run[-1]][1] + 3_000_000
     other = {}
     for r in rows:
-        if lo <= r[0] <= hi and "lstm_wavefront" not in r[2]:
+        if lo <= r[0] <= hi and not ("lstm_w" in r[2] or "lstm_thin" in r[2] or "rec_step" in r[2]):
             other.setdefault(r[2][:60], []).append(r[1] - r[0])
     for k, v in other.items():
         print("  near the pass: %-60s n=%d total %.3f ms" % (k, len(v), sum(v) / 1e6))
