@@ -877,9 +877,11 @@ __global__ __launch_bounds__(512, 4) void lstm_wavefront_kernel(const LstmWavefr
 // ---------------------------------------------------------------------------------------------------
 constexpr int LSTM_WREG_ROWS = 96;        // row capacity of the LDS tiles (6 row tiles)
 constexpr size_t LSTM_WREG_LDS = 2 * LSTM_WREG_ROWS * LSTM_LDA * sizeof(float);   // 101,376 B; the gate exchange buffer aliases it after the K loop
+constexpr int LSTM_WREG_PAIR_ROWS = 48;   // two-blocks-per-CU form: 3 row tiles
+constexpr size_t LSTM_WREG_PAIR_LDS = 2 * LSTM_WREG_PAIR_ROWS * LSTM_LDA * sizeof(float);   // 50,688 B
 
-template <int NT>
-__device__ __forceinline__ void lstm_wreg_body(const LstmLayerStep& Ls, int U_pad, int ut, int row0, float* smem)
+template <int NT, int D>
+__device__ __forceinline__ void lstm_wreg_body(const LstmLayerStep& Ls, int U_pad, int ut, int row0, float* smem, int tile_rows)
 {
     constexpr int ROWS = NT * 16;
     constexpr int EP = (ROWS * 16 + 511) / 512;       // epilogue items per thread
@@ -890,7 +892,7 @@ __device__ __forceinline__ void lstm_wreg_body(const LstmLayerStep& Ls, int U_pa
     const int ldg = 4 * U_pad;
     const int first = Ls.first, n_active = Ls.n_active;
     float* sA0 = smem;
-    float* sA1 = smem + LSTM_WREG_ROWS * LSTM_LDA;
+    float* sA1 = smem + tile_rows * LSTM_LDA;
 
     float gpre[EP][4], cprev[EP];
 #pragma unroll
@@ -910,8 +912,7 @@ __device__ __forceinline__ void lstm_wreg_body(const LstmLayerStep& Ls, int U_pa
     const int nb = nb0 + (first ? 0 : U_pad / LSTM_KB);    // a multiple of 4 (launcher)
     if (nb > 0) {
         // A chunk e of a batch = row tile e: thread -> (row = idx / 32, 16-B column idx % 32)
-        constexpr int D = NT >= 6 ? 2 : 4;   // weight batches in flight (6 tiles: 2.6 us of MFMA per batch already covers a round trip; 4 would spill)
-        f32x4 av[2][NT], wv[D][LSTM_KS];
+        f32x4 av[2][NT], wv[D][LSTM_KS];   // D = weight batches in flight
         auto load_a = [&](int b, f32x4 (&dst)[NT]) {
             b = b < nb ? b : nb - 1;       // past the end: re-fetch the last batch (never consumed), keeps the loop branch-free
             const float* ap; int K;
@@ -998,7 +999,11 @@ __device__ __forceinline__ void lstm_wreg_body(const LstmLayerStep& Ls, int U_pa
     }
 }
 
-__global__ __launch_bounds__(512) void lstm_wreg_kernel(const LstmWavefrontArgs args)
+// PAIR = false: one block per CU (up to 256 VGPRs), 1..6 row tiles, 4 weight batches in flight (2 at 6 tiles: 2.6 us of
+// MFMA per batch already covers a round trip, 4 would spill).  PAIR = true: two co-resident blocks per CU (128 VGPRs),
+// 1..3 row tiles, 2 batches in flight: one block's barrier bubbles are filled by the other's MFMAs.
+template <bool PAIR>
+__global__ __launch_bounds__(512, PAIR ? 4 : 2) void lstm_wreg_kernel(const LstmWavefrontArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) float wreg_smem[];
     int li = 0;
@@ -1013,14 +1018,23 @@ __global__ __launch_bounds__(512) void lstm_wreg_kernel(const LstmWavefrontArgs 
     const int row0 = rt * Ls.tpb * 16;
     const int tiles_left = (Ls.n_active - row0 + 15) / 16;
     const int ntile = tiles_left < Ls.tpb ? tiles_left : Ls.tpb;
-    switch (ntile) {   // uniform per block
-    case 1: lstm_wreg_body<1>(Ls, U_pad, ut, row0, wreg_smem); break;
-    case 2: lstm_wreg_body<2>(Ls, U_pad, ut, row0, wreg_smem); break;
-    case 3: lstm_wreg_body<3>(Ls, U_pad, ut, row0, wreg_smem); break;
-    case 4: lstm_wreg_body<4>(Ls, U_pad, ut, row0, wreg_smem); break;
-    case 5: lstm_wreg_body<5>(Ls, U_pad, ut, row0, wreg_smem); break;
-    case 6: lstm_wreg_body<6>(Ls, U_pad, ut, row0, wreg_smem); break;
-    default: break;
+    if (PAIR) {
+        switch (ntile) {   // uniform per block
+        case 1: lstm_wreg_body<1, 2>(Ls, U_pad, ut, row0, wreg_smem, LSTM_WREG_PAIR_ROWS); break;
+        case 2: lstm_wreg_body<2, 2>(Ls, U_pad, ut, row0, wreg_smem, LSTM_WREG_PAIR_ROWS); break;
+        case 3: lstm_wreg_body<3, 2>(Ls, U_pad, ut, row0, wreg_smem, LSTM_WREG_PAIR_ROWS); break;
+        default: break;
+        }
+    } else {
+        switch (ntile) {
+        case 1: lstm_wreg_body<1, 4>(Ls, U_pad, ut, row0, wreg_smem, LSTM_WREG_ROWS); break;
+        case 2: lstm_wreg_body<2, 4>(Ls, U_pad, ut, row0, wreg_smem, LSTM_WREG_ROWS); break;
+        case 3: lstm_wreg_body<3, 4>(Ls, U_pad, ut, row0, wreg_smem, LSTM_WREG_ROWS); break;
+        case 4: lstm_wreg_body<4, 4>(Ls, U_pad, ut, row0, wreg_smem, LSTM_WREG_ROWS); break;
+        case 5: lstm_wreg_body<5, 4>(Ls, U_pad, ut, row0, wreg_smem, LSTM_WREG_ROWS); break;
+        case 6: lstm_wreg_body<6, 2>(Ls, U_pad, ut, row0, wreg_smem, LSTM_WREG_ROWS); break;
+        default: break;
+        }
     }
 }
 
@@ -1142,7 +1156,9 @@ static int lstm_wreg_mode()
 
 hipError_t init_lstm_kernels()
 {
-    hipError_t we = hipFuncSetAttribute((const void*)lstm_wreg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_WREG_LDS);
+    hipError_t we = hipFuncSetAttribute((const void*)lstm_wreg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_WREG_LDS);
+    if (we != hipSuccess) return we;
+    we = hipFuncSetAttribute((const void*)lstm_wreg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_WREG_PAIR_LDS);
     if (we != hipSuccess) return we;
     hipError_t e = hipFuncSetAttribute((const void*)lstm_thin_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_THIN_LDS_MAX);
     if (e != hipSuccess) return e;
@@ -1204,22 +1220,30 @@ hipError_t launch_lstm_wavefront(hipStream_t s, LstmWavefrontArgs& a)
         if (Kl[l] % (4 * LSTM_KB)) wreg = false;
     }
     if (wreg) {
-        int best_f = 4, best_p = 4; float best = 1e30f;
-        for (int cf = 6; cf >= 1; --cf)
-            for (int cp = 6; cp >= 1; --cp) {
-                int blocks = 0; float work = 0.0f; bool any_part = false, any_full = false;
-                for (int l = 0; l < a.n; ++l) {
-                    const bool part = Kl[l] < Kmax;
-                    any_part |= part; any_full |= !part;
-                    const int cand = part ? cp : cf;
-                    blocks += lstm_blocks_for(a.L[l].n_active, a.U_pad, cand);
-                    work = std::max(work, cand * (float)Kl[l] / (8 * LSTM_KB));
+        int best_f = 4, best_p = 4; float best = 1e30f; bool best_pair = false;
+        const int pair_mode = lstm_wreg_mode();   // 1: choose by the cost model, 2: never pair, 3: always pair (A/B measurements)
+        for (int pair = 0; pair < 2; ++pair) {
+            if ((pair && pair_mode == 2) || (!pair && pair_mode == 3)) continue;
+            const int tmax = pair ? 3 : 6;
+            for (int cf = tmax; cf >= 1; --cf)
+                for (int cp = tmax; cp >= 1; --cp) {
+                    int blocks = 0; float work = 0.0f; bool any_part = false, any_full = false;
+                    for (int l = 0; l < a.n; ++l) {
+                        const bool part = Kl[l] < Kmax;
+                        any_part |= part; any_full |= !part;
+                        const int cand = part ? cp : cf;
+                        blocks += lstm_blocks_for(a.L[l].n_active, a.U_pad, cand);
+                        work = std::max(work, cand * (float)Kl[l] / (8 * LSTM_KB));
+                    }
+                    if ((!any_part && cp != tmax) || (!any_full && cf != tmax)) continue;
+                    // one block per CU: rounds of 256 blocks, each paying its fixed cost in full; two per CU: rounds of 512,
+                    // a CU's two blocks share the matrix pipe (2 x work) and hide each other's fixed cost
+                    const int rounds = (blocks + (pair ? 511 : 255)) / (pair ? 512 : 256);
+                    const bool two = pair && blocks > 256;
+                    const float cost = pair ? rounds * ((two ? 2.0f : 1.0f) * work + 1.0f) : rounds * (work + 1.5f);
+                    if (cost < best - 1e-6f) { best = cost; best_f = cf; best_p = cp; best_pair = pair != 0; }
                 }
-                if ((!any_part && cp != 6) || (!any_full && cf != 6)) continue;
-                const int rounds = (blocks + 255) / 256;
-                const float cost = rounds * (work + 1.5f);
-                if (cost < best - 1e-6f) { best = cost; best_f = cf; best_p = cp; }
-            }
+        }
         int total = 0;
         for (int l = 0; l < a.n; ++l) {
             const int tpb = Kl[l] < Kmax ? best_p : best_f;
@@ -1229,7 +1253,8 @@ hipError_t launch_lstm_wavefront(hipStream_t s, LstmWavefrontArgs& a)
             total += 8 * a.ut_groups * n_rt;
         }
         if (total == 0) return hipSuccess;
-        hipLaunchKernelGGL(lstm_wreg_kernel, dim3(total), dim3(512), LSTM_WREG_LDS, s, a);
+        if (best_pair) hipLaunchKernelGGL(lstm_wreg_kernel<true>, dim3(total), dim3(512), LSTM_WREG_PAIR_LDS, s, a);
+        else hipLaunchKernelGGL(lstm_wreg_kernel<false>, dim3(total), dim3(512), LSTM_WREG_LDS, s, a);
         return hipGetLastError();
     }
     int tpb_full = 4, tpb_part = 4;   // layers with K == Kmax / with a shorter K
