@@ -53,6 +53,8 @@ const char* am_version(void);
 /* replaces chainer.cuda.get_device_from_id(gpu).use() / model.to_gpu() (predict_folds.py:158-161,
  * evaluateModelForTest.py:47-50).  Fails with AM_ENODEV when `device` is not a gfx950 GPU. */
 int am_engine_create(int device, am_engine** out);
+/* Models, pipelines and decoders keep their engine alive: destroying the engine first only closes it (nothing new can be
+ * created on it); the device resources go when its last child is destroyed.  Handles may be destroyed in any order. */
 int am_engine_destroy(am_engine* e);
 int am_engine_synchronize(am_engine* e);
 int am_engine_device_name(am_engine* e, char* buf, int buflen);

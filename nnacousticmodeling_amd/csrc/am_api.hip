@@ -82,6 +82,10 @@ struct am_engine {
     double prof_ms[AM_KERNEL_ID_MAX] = {};
     char name[256] = {};
     DevBuf scratch[4];  // stand-alone stage entry points
+    // models, pipelines and decoders keep their engine alive: am_engine_destroy before the last of them only marks the
+    // engine closed, the last child's destroy then tears it down (host bindings finalise objects in no particular order)
+    int children = 0;
+    bool closed = false;
 };
 
 struct Layer {
@@ -263,9 +267,24 @@ extern "C" int am_engine_create(int device, am_engine** out)
     return AM_OK;
 }
 
+static void engine_teardown(am_engine* e);
+
 extern "C" int am_engine_destroy(am_engine* e)
 {
     if (!e) return AM_OK;
+    if (e->closed) return AM_OK;
+    e->closed = true;
+    if (e->children == 0) engine_teardown(e);
+    return AM_OK;
+}
+
+static void engine_child_gone(am_engine* e)
+{
+    if (--e->children == 0 && e->closed) engine_teardown(e);
+}
+
+static void engine_teardown(am_engine* e)
+{
     (void)hipSetDevice(e->device);
     (void)hipStreamSynchronize(e->stream);
     (void)hipStreamSynchronize(e->stream2);
@@ -278,7 +297,6 @@ extern "C" int am_engine_destroy(am_engine* e)
     e->d_overflow.release();
     (void)hipStreamDestroy(e->stream);
     delete e;
-    return AM_OK;
 }
 
 extern "C" int am_engine_synchronize(am_engine* e)
@@ -400,6 +418,7 @@ extern "C" int am_model_create(am_engine* e, int kind, int n_layers, int activat
     if (!out) return fail(AM_EINVAL, "am_model_create: out is NULL");
     *out = nullptr;
     if (!e || !in_dims || !out_dims || !W || !b) return fail(AM_EINVAL, "am_model_create: NULL argument");
+    if (e->closed) return fail(AM_EINVAL, "the engine has been destroyed");
     if (kind != AM_NET_FF && kind != AM_NET_LSTM) return fail(AM_EINVAL, "am_model_create: unknown network kind %d", kind);
     if (n_layers < 0 || n_layers > 64) return fail(AM_EINVAL, "am_model_create: bad layer count %d", n_layers);
     if (kind == AM_NET_FF && (activation < AM_ACT_RELU || activation > AM_ACT_TANH)) return fail(AM_EINVAL, "Wrong activation function specified");
@@ -418,7 +437,7 @@ extern "C" int am_model_create(am_engine* e, int kind, int n_layers, int activat
     }
     HIP_TRY(hipSetDevice(e->device));
     am_model* m = new am_model();
-    m->e = e; m->kind = kind; m->n_layers = n_layers; m->act = activation;
+    m->e = e; ++e->children; m->kind = kind; m->n_layers = n_layers; m->act = activation;
     m->L.resize(n_layers + 1);
     m->in_dim = in_dims[0];
     m->in_pad = (int)round_up(in_dims[0], GEMM_BK);
@@ -472,7 +491,9 @@ extern "C" int am_model_destroy(am_model* m)
         l.W.release(); l.b.release(); l.Wlat.release(); l.Whi.release(); l.Wlo.release(); l.b_s.release();
         l.WA.release(); l.WB.release(); l.bA_first.release(); l.bA_rest.release(); l.bB_first.release(); l.bB_rest.release();
     }
+    am_engine* e = m->e;
     delete m;
+    engine_child_gone(e);
     return AM_OK;
 }
 
@@ -485,6 +506,7 @@ extern "C" int am_model_create_tdnn(am_engine* e, int n_layers, int activation, 
     if (!out) return fail(AM_EINVAL, "am_model_create_tdnn: out is NULL");
     *out = nullptr;
     if (!e || !units || !ksize || !W || !b || !out_W || !out_b) return fail(AM_EINVAL, "am_model_create_tdnn: NULL argument");
+    if (e->closed) return fail(AM_EINVAL, "the engine has been destroyed");
     if (n_layers < 1 || n_layers > 64) return fail(AM_EINVAL, "am_model_create_tdnn: bad layer count %d", n_layers);
     if (activation < AM_ACT_RELU || activation > AM_ACT_TANH) return fail(AM_EINVAL, "Wrong activation function specified");
     if (in_channels <= 0 || n_classes <= 0) return fail(AM_EINVAL, "am_model_create_tdnn: bad dimension");
@@ -495,7 +517,7 @@ extern "C" int am_model_create_tdnn(am_engine* e, int n_layers, int activation, 
     }
     HIP_TRY(hipSetDevice(e->device));
     am_model* m = new am_model();
-    m->e = e; m->kind = AM_NET_FF; m->tdnn = true; m->n_layers = n_layers; m->act = activation;
+    m->e = e; ++e->children; m->kind = AM_NET_FF; m->tdnn = true; m->n_layers = n_layers; m->act = activation;
     m->win = win; m->tdnn_D = in_channels;
     m->in_dim = in_channels * win;
     m->in_pad = (int)round_up(in_channels, 32);   // channels per position of the channel-last input
@@ -545,6 +567,7 @@ extern "C" int am_model_create_rnn(am_engine* e, int cell, int n_layers, int act
     *out = nullptr;
     const int np = cell_param_count(cell);
     if (!e || !params || !out_W || !out_b) return fail(AM_EINVAL, "am_model_create_rnn: NULL argument");
+    if (e->closed) return fail(AM_EINVAL, "the engine has been destroyed");
     if (np == 0) return fail(AM_EINVAL, "am_model_create_rnn: unknown cell %d", cell);
     if (n_layers < 1 || n_layers > LSTM_MAX_LAYERS) return fail(AM_EINVAL, "am_model_create_rnn: 1..%d layers are supported", LSTM_MAX_LAYERS);
     if (in_dim <= 0 || units <= 0 || n_classes <= 0) return fail(AM_EINVAL, "am_model_create_rnn: bad dimension");
@@ -553,7 +576,7 @@ extern "C" int am_model_create_rnn(am_engine* e, int cell, int n_layers, int act
         if (!params[i]) return fail(AM_EINVAL, "am_model_create_rnn: parameter %d of layer %d is NULL", i % np, i / np);
     HIP_TRY(hipSetDevice(e->device));
     am_model* m = new am_model();
-    m->e = e; m->kind = AM_NET_LSTM; m->cell = cell; m->n_layers = n_layers; m->act = activation;
+    m->e = e; ++e->children; m->kind = AM_NET_LSTM; m->cell = cell; m->n_layers = n_layers; m->act = activation;
     m->L.resize(n_layers + 1);
     m->in_dim = in_dim;
     m->in_pad = (int)round_up(in_dim, 64);
@@ -634,8 +657,9 @@ extern "C" int am_model_create_rnn(am_engine* e, int cell, int n_layers, int act
 extern "C" int am_pipeline_create(am_engine* e, am_pipeline** out)
 {
     if (!e || !out) return fail(AM_EINVAL, "am_pipeline_create: NULL argument");
+    if (e->closed) return fail(AM_EINVAL, "the engine has been destroyed");
     am_pipeline* p = new am_pipeline();
-    p->e = e;
+    p->e = e; ++e->children;
     *out = p;
     return AM_OK;
 }
@@ -651,7 +675,9 @@ extern "C" int am_pipeline_destroy(am_pipeline* p)
     for (DevBuf* d : {&p->d_shifts, &p->d_add, &p->d_scale, &p->d_rplw, &p->d_rplb, &p->d_rpllb, &p->d_prior, &p->d_x, &p->d_ivec, &p->d_in, &p->d_in_s,
                       &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c})
         d->release();
+    am_engine* e = p->e;
     delete p;
+    engine_child_gone(e);
     return AM_OK;
 }
 
@@ -1456,6 +1482,8 @@ struct am_decoder {
     int P = 0, B = 0, T = 0, S = 0;
     float PIP = 0.f;
     DevBuf endIdx, tri_idx, tri_self, tri_trans, outOff, outVal, lm, p0;
+    DevBuf cmp0, cmp1;   // compact 32-B graph records (nodes and posterior columns < 65536), see viterbi_compact_kernel
+    bool has_compact = false;
     DevBuf d_lp, d_off, pp, tt, pout, p, bestI, bestT, seg_begin, seg_end, seg_tri, seg_count;
 };
 
@@ -1477,6 +1505,7 @@ extern "C" int am_decoder_create(am_engine* e, int numPhones, int numBiphones, i
     if (!e || numPhones <= 0 || numBiphones <= 0 || numTriphones <= 0 || numStates <= 0 || !startIdxs || !endIdxs || !biphoneIdxIn ||
         !stateIdxs || !tpSelfloop || !tpTransition || !outOffsets || !outValues || !lm)
         return fail(AM_EINVAL, "am_decoder_create: bad argument");
+    if (e->closed) return fail(AM_EINVAL, "the engine has been destroyed");
     const int P = numPhones, B = numBiphones, T = numTriphones;
     // validate every index once on the host: the kernel then needs no bounds checks
     for (int i = 0; i < P; ++i)
@@ -1493,7 +1522,7 @@ extern "C" int am_decoder_create(am_engine* e, int numPhones, int numBiphones, i
         if (outValues[i] < 0 || outValues[i] >= T) return fail(AM_EINVAL, "am_decoder_create: outValues[%d] out of range", i);
     HIP_TRY(hipSetDevice(e->device));
     am_decoder* d = new am_decoder();
-    d->e = e; d->P = P; d->B = B; d->T = T; d->S = numStates; d->PIP = PIP;
+    d->e = e; ++e->children; d->P = P; d->B = B; d->T = T; d->S = numStates; d->PIP = PIP;
     std::vector<float> lms(B), p0(B, -1e20f);
     for (int i = 0; i < B; ++i) lms[i] = lm[i] * LMW;                                     // phone_recog.cpp:112
     for (int i = 0; i < P; ++i) p0[startIdxs[i]] = (float)((double)lms[startIdxs[i]] - log((double)(float)P));  // phone_recog.cpp:148
@@ -1509,6 +1538,23 @@ extern "C" int am_decoder_create(am_engine* e, int numPhones, int numBiphones, i
         }
     }
     int rc = AM_OK;
+    if (B < 65536 && numStates < 65536) {
+        std::vector<int> c0(4 * (size_t)T);
+        std::vector<float> c1(4 * (size_t)T);
+        for (int n = 0; n < T; ++n) {
+            c0[4 * n] = biphoneIdxIn[n] | (stateIdxs[3 * n] << 16);
+            c0[4 * n + 1] = stateIdxs[3 * n + 1] | (stateIdxs[3 * n + 2] << 16);
+            memcpy(&c0[4 * n + 2], &tpSelfloop[3 * n], sizeof(float));
+            memcpy(&c0[4 * n + 3], &tpSelfloop[3 * n + 1], sizeof(float));
+            c1[4 * n] = tpSelfloop[3 * n + 2];
+            c1[4 * n + 1] = tpTransition[3 * n]; c1[4 * n + 2] = tpTransition[3 * n + 1]; c1[4 * n + 3] = tpTransition[3 * n + 2];
+        }
+        if ((rc = upload_raw(e, d->cmp0, c0.data(), c0.size())) != AM_OK || (rc = upload_raw(e, d->cmp1, c1.data(), c1.size())) != AM_OK) {
+            am_decoder_destroy(d);
+            return rc;
+        }
+        d->has_compact = true;
+    }
     if ((rc = upload_raw(e, d->endIdx, endIdxs, P)) == AM_OK && (rc = upload_raw(e, d->tri_idx, tidx.data(), tidx.size())) == AM_OK &&
         (rc = upload_raw(e, d->tri_self, tself.data(), tself.size())) == AM_OK && (rc = upload_raw(e, d->tri_trans, ttrans.data(), ttrans.size())) == AM_OK &&
         (rc = upload_raw(e, d->outOff, outOffsets, (size_t)B + 1)) == AM_OK &&
@@ -1525,10 +1571,12 @@ extern "C" int am_decoder_destroy(am_decoder* d)
     if (!d) return AM_OK;
     (void)hipSetDevice(d->e->device);
     (void)hipStreamSynchronize(d->e->stream);
-    for (DevBuf* b : {&d->endIdx, &d->tri_idx, &d->tri_self, &d->tri_trans, &d->outOff, &d->outVal, &d->lm, &d->p0, &d->d_lp, &d->d_off,
+    for (DevBuf* b : {&d->cmp0, &d->cmp1, &d->endIdx, &d->tri_idx, &d->tri_self, &d->tri_trans, &d->outOff, &d->outVal, &d->lm, &d->p0, &d->d_lp, &d->d_off,
                       &d->pp, &d->tt, &d->pout, &d->p, &d->bestI, &d->bestT, &d->seg_begin, &d->seg_end, &d->seg_tri, &d->seg_count})
         b->release();
+    am_engine* e = d->e;
     delete d;
+    engine_child_gone(e);
     return AM_OK;
 }
 
@@ -1556,6 +1604,13 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
     a.P = d->P; a.B = d->B; a.T = d->T;
     a.endIdx = d->endIdx.as<int>();
     a.tri_idx = (decltype(a.tri_idx))d->tri_idx.p; a.tri_self = (decltype(a.tri_self))d->tri_self.p; a.tri_trans = (decltype(a.tri_trans))d->tri_trans.p;
+    int64_t longest = 0;
+    for (int u = 0; u < n_utts; ++u) longest = std::max(longest, offsets[u + 1] - offsets[u]);
+    static const int64_t compact_ok = env_int("AM_VITERBI_COMPACT", 1);
+    if (d->has_compact && longest < 65535 && compact_ok) {   // entry times travel as 16-bit (t + 1)
+        a.compact = 1;
+        a.tri_idx = (decltype(a.tri_idx))d->cmp0.p; a.tri_self = (decltype(a.tri_self))d->cmp1.p;
+    }
     a.outOff = d->outOff.as<int>(); a.outVal = d->outVal.as<int>();
     a.lm = d->lm.as<float>(); a.p0 = d->p0.as<float>(); a.PIP = d->PIP;
     a.lp = lp_dev; a.ldl = ld; a.offsets = d->d_off.as<long long>();

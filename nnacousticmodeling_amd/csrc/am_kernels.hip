@@ -1553,10 +1553,111 @@ __global__ __launch_bounds__(1024) void viterbi_kernel(const ViterbiArgs a)
     }
 }
 
+// Compact form (graphs with < 65536 nodes and posterior columns, utterances < 65535 frames -- every TIMIT-sized set-up):
+// the decoder is bound by the bytes it streams per triphone and frame, so the records shrink from 116 B to 76 B:
+//   graph  c0 = {node | col0 << 16, col1 | col2 << 16, self0, self1}, c1 = {self2, trans0, trans1, trans2}   (32 B, was 48)
+//   state  {score0, score1, score2, (t0+1) | (t1+1) << 16} (16 B) + (t2+1) (4 B) read, the same + exit score written
+// and every thread handles two triphones per trip (twice the loads in flight: the tail of the run belongs to the longest
+// utterances, one CU each, where the per-CU memory parallelism is the limit).  Same arithmetic, same comparisons, same
+// tie-breaking as viterbi_kernel: bit-identical segmentations.
+__device__ __forceinline__ void viterbi_tri_update(const i32x4 c0, const f32x4 c1, const i32x4 q, const int t2s, const float* __restrict__ p,
+                                                    const float* __restrict__ lp1, float PIP, int k, i32x4& nq, int& nt2, float& po)
+{
+    const int node = c0[0] & 0xffff, col0 = (unsigned)c0[0] >> 16, col1 = c0[1] & 0xffff, col2 = (unsigned)c0[1] >> 16;
+    const float sl0 = __int_as_float(c0[2]), sl1 = __int_as_float(c0[3]), sl2 = c1[0];
+    const float tr0 = c1[1], tr1 = c1[2], tr2 = c1[3];
+    const float q0 = __int_as_float(q[0]), q1 = __int_as_float(q[1]), q2 = __int_as_float(q[2]);
+    const int t0s = q[3] & 0xffff, t1s = (unsigned)q[3] >> 16;   // entry times + 1
+    const float pIn = p[node] + PIP;
+    const float st0 = q0 + sl0, st1 = q1 + sl1, st2 = q2 + sl2;
+    const float go0 = pIn, go1 = q0 + tr0, go2 = q1 + tr1;
+    const float e0 = lp1[col0], e1 = lp1[col1], e2 = lp1[col2];
+    float n0, n1, n2; int nt0, nt1;
+    if (go2 > st2) { n2 = go2 + e2; nt2 = t1s; } else { n2 = st2 + e2; nt2 = t2s; }
+    if (go1 > st1) { n1 = go1 + e1; nt1 = t0s; } else { n1 = st1 + e1; nt1 = t1s; }
+    if (go0 > st0) { n0 = go0 + e0; nt0 = k; } else { n0 = st0 + e0; nt0 = t0s; }   // k = (k - 1) + 1
+    nq[0] = __float_as_int(n0); nq[1] = __float_as_int(n1); nq[2] = __float_as_int(n2); nq[3] = nt0 | (nt1 << 16);
+    po = n2 + tr2;
+}
+
+__global__ __launch_bounds__(1024) void viterbi_compact_kernel(const ViterbiArgs a)
+{
+    const int u = blockIdx.x, tid = threadIdx.x;
+    const long long row0 = a.offsets[u];
+    const int N = (int)(a.offsets[u + 1] - row0);
+    const int T = a.T, B = a.B;
+    i32x4* pp = (i32x4*)a.pp + (size_t)u * T;      // {3 scores, t0+1 | t1+1 << 16}
+    int* t2 = a.tt + (size_t)u * T;                // t2 + 1
+    float* pout = a.pout + (size_t)u * T;
+    float* p = a.p + (size_t)u * B;
+    int* bI = a.bestI + (size_t)row0 * B;
+    int* bT = a.bestT + (size_t)row0 * B;
+    const i32x4* c0 = (const i32x4*)a.tri_idx;
+    const f32x4* c1 = (const f32x4*)a.tri_self;
+    const float NINF = -1e20f;
+    const int ninf = __float_as_int(NINF);
+    for (int i = tid; i < B; i += 1024) p[i] = a.p0[i];
+    for (int i = tid; i < T; i += 1024) { pp[i] = (i32x4){ninf, ninf, ninf, 1 | (1 << 16)}; t2[i] = 1; }   // entry times 0
+    __syncthreads();
+    for (int k = 0; k < N; ++k) {
+        const float* lp1 = a.lp + (size_t)(row0 + k) * a.ldl;
+        for (int n = tid; n < T; n += 2048) {
+            const bool two = n + 1024 < T;
+            const int m = two ? n + 1024 : n;
+            const i32x4 ga = c0[n], gb = c0[m];
+            const f32x4 ha = c1[n], hb = c1[m];
+            const i32x4 qa = pp[n], qb = pp[m];
+            const int ta = t2[n], tb = t2[m];
+            i32x4 nqa, nqb; int nta, ntb; float poa, pob;
+            viterbi_tri_update(ga, ha, qa, ta, p, lp1, a.PIP, k, nqa, nta, poa);
+            viterbi_tri_update(gb, hb, qb, tb, p, lp1, a.PIP, k, nqb, ntb, pob);
+            pp[n] = nqa; t2[n] = nta; pout[n] = poa;
+            if (two) { pp[m] = nqb; t2[m] = ntb; pout[m] = pob; }
+        }
+        __syncthreads();
+        for (int i = tid; i < B; i += 1024) {
+            int mxi = 0;
+            float mx = NINF;
+            for (int s = a.outOff[i]; s < a.outOff[i + 1]; ++s) {
+                const int ids = a.outVal[s];
+                const float pOut = pout[ids];
+                if (mx < pOut) { mx = pOut; mxi = ids; }
+            }
+            p[i] = mx + a.lm[i];
+            bI[(size_t)k * B + i] = mxi;
+            bT[(size_t)k * B + i] = t2[mxi] - 1;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int mxi = 0;
+        float mx = NINF;
+        for (int i = 0; i < a.P; ++i) {
+            const int ids = a.endIdx[i];
+            if (mx < p[ids]) { mx = p[ids]; mxi = ids; }
+        }
+        int count = 0, t = N - 1;
+        bool ok = true;
+        while (t >= 0) {
+            if (count >= N) { ok = false; break; }       // the reference would loop forever here
+            const int id = bI[(size_t)t * B + mxi];
+            const int end = t + 1;
+            t = bT[(size_t)t * B + mxi];
+            a.seg_end[row0 + count] = end;
+            a.seg_begin[row0 + count] = t + 1;
+            a.seg_tri[row0 + count] = id;
+            mxi = c0[id][0] & 0xffff;
+            ++count;
+        }
+        a.seg_count[u] = ok ? count : 0;
+    }
+}
+
 hipError_t launch_viterbi(hipStream_t s, const ViterbiArgs& a, int n_utts)
 {
     if (n_utts <= 0) return hipSuccess;
-    hipLaunchKernelGGL(viterbi_kernel, dim3(n_utts), dim3(1024), 0, s, a);
+    if (a.compact) hipLaunchKernelGGL(viterbi_compact_kernel, dim3(n_utts), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL(viterbi_kernel, dim3(n_utts), dim3(1024), 0, s, a);
     return hipGetLastError();
 }
 

@@ -115,3 +115,25 @@ def test_linear_identity_asymmetric(eng):
     x = np.eye(k, dtype=np.float32)
     w = (np.arange(160 * k, dtype=np.float32).reshape(160, k) % 251) - 125
     assert np.array_equal(eng.linear(x, w), w.T)
+
+
+def test_handles_may_be_destroyed_in_any_order():
+    """Host bindings finalise objects in no particular order (interpreter exit): an engine destroyed before its model,
+    pipeline and decoder must stay usable for their destruction (am_engine_destroy only closes it)."""
+    from nnacousticmodeling_amd.engine import Engine, Model, Pipeline
+    from nnacousticmodeling_amd.phone_recog import PhoneRecog
+    from oracle import viterbi_oracle as vo
+    rng = np.random.default_rng(0)
+    eng = Engine(0)
+    m = Model(eng, "ff", 1, orc.make_mlp_params(rng, 40, 32, 1, 39))
+    p = Pipeline(eng)
+    p.set_frontend(40, [0])
+    p.set_members([m])
+    y = p.forward_ff(rng.standard_normal((10, 40)).astype(np.float32))
+    graph = vo.make_graph(rng, 3, 12)
+    dec = PhoneRecog(eng, dict(graph, numPhones=3, numBiphones=len(graph["lm"]), numTriphones=len(graph["biphoneIdxIn"])), -1.0, 1.0)
+    eng.close()          # first
+    p.close()
+    dec.close()
+    m.close()            # last child: the engine's resources go here
+    assert y.shape == (10, 39)
