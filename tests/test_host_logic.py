@@ -227,6 +227,31 @@ def test_evaluate_cli_ff_ensemble_writes_reference_files(tmp_path, fake_runners,
         assert np.array_equal(got, orc.load_bin(str(path)))
 
 
+@pytest.mark.parametrize("network", ["tdnn", "gru", "peepholelstm"])
+def test_evaluate_cli_other_networks(tmp_path, fake_runners, real_ft_path, real_priors, network):
+    """evaluate.py's own branches for the networks beyond ff/lstm: tdnn takes its splice from --tdnn-ksize and tiles the
+    centre-frame transform (evaluate.py:138-159); recurrent cells keep the centre frame only and ignore --timedelay (M6)."""
+    rng = np.random.default_rng(9)
+    data_dir, recog_dir, lab_dir, off, x, names = _eval_dirs(tmp_path, real_ft_path, real_priors, 4, 90, rng)
+    full = orc.load_kaldi_feature_transform(real_ft_path)
+    if network == "tdnn":
+        ksize, units = [3, 3], [10, 12]
+        params = orc.make_tdnn_params(rng, 40, units, ksize, 1909)
+        ft = orc.tdnn_frame_transform(full, ksize)
+        data, net_args, omodel = orc.evaluate_frontend(x, 2, ft), ["-u", *units, "--tdnn-ksize", *ksize, "--splice", 5], orc.TDNN(params, 2)
+    else:
+        params = orc.make_gru_params(rng, 40, 12, 2, 1909) if network == "gru" else orc.make_peephole_params(rng, 40, 12, 2, 1909)
+        ft = orc.centre_frame_transform(full)
+        data, net_args, omodel = orc.evaluate_frontend(x, 0, ft), ["-u", 12, "--timedelay", 4], orc.get_nn(network, 2, params)
+    chainer_npz.write_npz(tmp_path / "model", params)
+    per = evaluate.main(["-n", network, "-l", 2, *net_args, "--tri", "--ft", "final.feature_transform", "--data-dir", data_dir, "--offset-dir", data_dir,
+                         "--utt-list-dir", data_dir, "--recog-dir", recog_dir, "-m", tmp_path / "model", "--tmp-dir", lab_dir, "--no-progress"])
+    assert np.isnan(per)
+    want = orc.evaluate_posteriors(omodel, data, off, ap=real_priors, rnn=network != "tdnn")
+    for u, name in enumerate(names):
+        assert np.max(np.abs(kw_io.loadBin(str(lab_dir / (name + ".lab"))) - want[u])) < 1e-5
+
+
 def test_evaluate_function_contract_pretransformed_data_and_lstm(tmp_path, fake_runners, real_ft_path, real_priors):
     """evaluateModelTestTri(model, data, ...) with `data` already spliced/transformed, as the reference passes it."""
     rng = np.random.default_rng(7)

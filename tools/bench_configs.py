@@ -106,6 +106,18 @@ def main():
             fl = 2 * (40 * 2048 + 2 * 512 * 2048 + 3 * 512 * 2048 + 512 * 1909)
             report("3x512 LSTM N=57919 192 utts Tmax=%d timedelay=%d" % (int(np.diff(offsets).max()), td), N, wall, ms, calls, fl)
             p.close()
+    if args.which in ("lstm1024",):
+        # the reference's own example network (scripts/examples: "lstm -l 4 -u 1024 --timedelay 5")
+        params = orc.make_lstm_params(rng, 40, 1024, 4, 1909)
+        m = Model(eng, "lstm", 4, params)
+        p = Pipeline(eng)
+        p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
+        p.set_members([m])
+        p.lstm_upload(x, None, offsets, 5)
+        wall, ms, calls = timed(eng, p.lstm_run, args.steps, 3)
+        fl = 2 * (40 * 4096 + 4 * 1024 * 4096 + 3 * 1024 * 4096 + 1024 * 1909)
+        report("4x1024 LSTM N=57919 192 utts timedelay=5", N, wall, ms, calls, fl)
+        p.close()
     if args.which in ("all", "tdnn"):
         # tsd2018's TDNN sweeps (scripts/papers/tsd2018/run.sh:22-30): 5-5-5-5 and 9-9-9-9 kernels, 1024 units
         for ksize in ([5, 5, 5, 5], [9, 9, 9, 9]):
