@@ -68,18 +68,26 @@ def evaluateModelTestTri(model, data, offsets, PIP, LMW, ap=None, GPUID=0, testO
     devices = list(GPUID) if isinstance(GPUID, (list, tuple)) else [GPUID]
     if progress:
         print("Calculating network outputs")
-    y = compute_posteriors(model, data, offsets, ap=ap, devices=devices, rnn=rnn, frontend=frontend, ivectors=ivectors)
+    img = str(Path(recogdir, "kaldiTri1909.img"))
+    # without .lab files and with the in-process decoder on one GPU nothing has to leave the device: the decoder reads the
+    # posteriors where the network wrote them (no 442 MB download + upload for the core test set)
+    resident = (not write_lab) and run_decoder in ("auto", "gpu") and len(devices) == 1 and os.path.isfile(img)
+    pipeline = y = None
+    if resident:
+        shifts, ft = ([0], None) if frontend is None else frontend
+        pipeline = get_runner(devices).resident(model, data, offsets, shifts=shifts, ft=ft, ivectors=ivectors, prior=ap, recurrent=rnn)
+    else:
+        y = compute_posteriors(model, data, offsets, ap=ap, devices=devices, rnn=rnn, frontend=frontend, ivectors=ivectors)
     labDirOut = Path(tmpDir)
     labDirOut.mkdir(exist_ok=True, parents=True)
     offsets = np.asarray(offsets)
     scp = Path(labDirOut, testOrDev + ".scp")
-    if write_lab or run_decoder == "subprocess":
+    if y is not None and (write_lab or run_decoder == "subprocess"):
         if progress:
             print("Writing output files")
         scp = write_posteriors(y, offsets, testList, labDirOut, testOrDev)
 
     recog = recogdir + "/PhoneRecog" + (".exe" if os.name == "nt" else "")
-    img = str(Path(recogdir, "kaldiTri1909.img"))
     result_txt = str(Path(labDirOut, "vysledek_" + testOrDev + ".txt"))
     if not run_decoder:
         return float("nan")
@@ -96,7 +104,7 @@ def evaluateModelTestTri(model, data, offsets, PIP, LMW, ap=None, GPUID=0, testO
         from .phone_recog import PhoneRecog, base_name_copy, write_mlf
         runner = get_runner(devices)
         dec = PhoneRecog(runner._dev(devices[0]).engine, img, -abs(PIP), LMW)
-        results = dec.recognise(y, offsets)
+        results = dec.recognise_pipeline(pipeline, offsets) if pipeline is not None else dec.recognise(y, offsets)
         names = [base_name_copy(str(Path(labDirOut, f.strip() + ".lab"))) for f in testList]
         write_mlf(result_txt, names, results)
         dec.close()

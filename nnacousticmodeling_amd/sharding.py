@@ -193,6 +193,27 @@ class PosteriorRunner:
             self._run_parallel(jobs)
         return y
 
+    # device-resident variants (single GPU): the posteriors stay in the pipeline's device memory -------------------
+    def resident(self, model, x, offsets=None, shifts=(0,), ft=None, ivectors=None, prior=None, recurrent=False, normalise=True):
+        """Upload + run without the download: returns the pipeline that now holds the [N, C] posteriors on the GPU
+        (``PhoneRecog.recognise_pipeline`` decodes them in place).  One device only."""
+        if len(self.devices) != 1:
+            raise ValueError("device-resident posteriors need a single-GPU runner")
+        ens = as_ensemble(model)
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        iv = None if ivectors is None else np.ascontiguousarray(ivectors, dtype=np.float32)
+        d_iv = 0 if iv is None else iv.shape[1]
+        st = self._dev(self.devices[0])
+        shifts = [0] if recurrent else [int(s) for s in shifts]
+        p = self._configure(st, ens, x.shape[1], shifts, ft, d_iv, prior, AM_COMBINE_LOGITS, normalise)
+        if recurrent:
+            p.lstm_upload(x, iv, np.asarray(offsets, dtype=np.int64), 0)
+            p.lstm_run()
+        else:
+            p.ff_upload(x, iv, x.shape[0], 0, 0)
+            p.ff_run()
+        return p
+
     def close(self):
         for st in self._state.values():
             st.pipeline.close()

@@ -109,6 +109,13 @@ def test_evaluate_end_to_end_with_gpu_decoder(engine, tmp_path, real_ft_path, re
         assert got[names[u]][1] == [b * 100000 for b, _, _ in want] and got[names[u]][2] == [e * 100000 for _, e, _ in want]
     want_per = scoring.computeWER(scoring.loadMlf(str(lab_dir / "vysledek_test_p39.txt")), scoring.loadMlf(str(recog_dir / "test_ref.mlf")), True)
     assert per == want_per
+    # --no-lab on one GPU: the posteriors never leave the device (resident pipeline -> recognise_pipeline); same MLF, same PER
+    mlf_with_lab = (lab_dir / "vysledek_test.txt").read_text()
+    lab2 = tmp_path / "lab_resident"
+    per2 = evaluate.main([a if a is not lab_dir else lab2 for a in base] + ["--no-lab"])
+    assert per2 == per
+    assert (lab2 / "vysledek_test.txt").read_text().replace(str(lab2), str(lab_dir)) == mlf_with_lab
+    assert not list(lab2.glob("*.lab"))
     # decoding straight from device memory gives the same segmentation as decoding the downloaded posteriors
     from nnacousticmodeling_amd.engine import Model, Pipeline
     p = Pipeline(engine)
