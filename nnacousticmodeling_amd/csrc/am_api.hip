@@ -1482,6 +1482,7 @@ struct am_decoder {
     int P = 0, B = 0, T = 0, S = 0;
     float PIP = 0.f;
     DevBuf endIdx, tri_idx, tri_self, tri_trans, outOff, outVal, lm, p0;
+    DevBuf d_slot;       // frame-synchronous form: slot -> utterance
     DevBuf cmp0, cmp1;   // compact 32-B graph records (nodes and posterior columns < 65536), see viterbi_compact_kernel
     bool has_compact = false;
     DevBuf d_lp, d_off, pp, tt, pout, p, bestI, bestT, seg_begin, seg_end, seg_tri, seg_count;
@@ -1571,7 +1572,7 @@ extern "C" int am_decoder_destroy(am_decoder* d)
     if (!d) return AM_OK;
     (void)hipSetDevice(d->e->device);
     (void)hipStreamSynchronize(d->e->stream);
-    for (DevBuf* b : {&d->cmp0, &d->cmp1, &d->endIdx, &d->tri_idx, &d->tri_self, &d->tri_trans, &d->outOff, &d->outVal, &d->lm, &d->p0, &d->d_lp, &d->d_off,
+    for (DevBuf* b : {&d->d_slot, &d->cmp0, &d->cmp1, &d->endIdx, &d->tri_idx, &d->tri_self, &d->tri_trans, &d->outOff, &d->outVal, &d->lm, &d->p0, &d->d_lp, &d->d_off,
                       &d->pp, &d->tt, &d->pout, &d->p, &d->bestI, &d->bestT, &d->seg_begin, &d->seg_end, &d->seg_tri, &d->seg_count})
         b->release();
     am_engine* e = d->e;
@@ -1616,6 +1617,22 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
     a.lp = lp_dev; a.ldl = ld; a.offsets = d->d_off.as<long long>();
     a.pp = d->pp.as<float>(); a.tt = d->tt.as<int>(); a.pout = d->pout.as<float>(); a.p = d->p.as<float>(); a.bestI = d->bestI.as<int>(); a.bestT = d->bestT.as<int>();
     a.seg_begin = d->seg_begin.as<int>(); a.seg_end = d->seg_end.as<int>(); a.seg_tri = d->seg_tri.as<int>(); a.seg_count = d->seg_count.as<int>();
+    static const int64_t fs_ok = env_int("AM_VITERBI_FS", 1);
+    if (a.compact && fs_ok && n_utts > 0) {
+        // frame-synchronous: slots = utterances by length (longest first); step k advances the first n_active slots
+        std::vector<int> order(n_utts);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return offsets[x + 1] - offsets[x] > offsets[y + 1] - offsets[y]; });
+        AM_TRY(upload_raw(e, d->d_slot, order.data(), order.size()));
+        a.slot_utt = d->d_slot.as<int>();
+        AM_TRY(run_kernel(e, K_VITERBI, [&] { return launch_viterbi_fs_init(e->stream, a, n_utts); }));
+        int active = n_utts;
+        for (int64_t k = 0; k < longest; ++k) {
+            while (active > 0 && offsets[order[active - 1] + 1] - offsets[order[active - 1]] <= k) --active;
+            AM_TRY(run_kernel(e, K_VITERBI, [&] { return launch_viterbi_fs_step(e->stream, a, (int)k, active); }));
+        }
+        AM_TRY(run_kernel(e, K_VITERBI, [&] { return launch_viterbi_fs_trace(e->stream, a, n_utts); }));
+    } else
     AM_TRY(run_kernel(e, K_VITERBI, [&] { return launch_viterbi(e->stream, a, n_utts); }));
     std::vector<int> hb(std::max<int64_t>(N, 1)), he(std::max<int64_t>(N, 1)), ht(std::max<int64_t>(N, 1));
     if (N > 0) {

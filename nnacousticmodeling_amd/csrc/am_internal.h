@@ -156,7 +156,13 @@ struct ViterbiArgs {
     int* bestI; int* bestT;            // [N][B] back-pointers
     int* seg_begin; int* seg_end; int* seg_tri;  // [N] segments of utterance u at [offsets[u], offsets[u] + seg_count[u]), last first
     int* seg_count;                    // [n_utts]
+    const int* slot_utt;               // frame-synchronous form: utterance of each slot (slots sorted by length, longest first)
 };
 hipError_t launch_viterbi(hipStream_t s, const ViterbiArgs& a, int n_utts);
+// frame-synchronous form (compact records only): init, one (triphone update + node maxima) launch pair per frame k over the
+// first n_active slots, back-trace of every utterance
+hipError_t launch_viterbi_fs_init(hipStream_t s, const ViterbiArgs& a, int n_utts);
+hipError_t launch_viterbi_fs_step(hipStream_t s, const ViterbiArgs& a, int k, int n_active);
+hipError_t launch_viterbi_fs_trace(hipStream_t s, const ViterbiArgs& a, int n_utts);
 
 }  // namespace am

@@ -1653,6 +1653,137 @@ __global__ __launch_bounds__(1024) void viterbi_compact_kernel(const ViterbiArgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Frame-synchronous form of the same decoder: the whole chip advances ALL active utterances by one frame per launch pair
+// (triphone update, then node maxima), like the recurrent path's wavefront.  One workgroup per utterance leaves the tail
+// of a run to a handful of CUs (the longest utterances) and HBM idle; here every launch streams the state of every active
+// utterance, so the pass is HBM-bound throughout.  Utterances are sorted by length (slots), the active ones are the first
+// n_active of a step.  Same records, arithmetic, comparisons and tie-breaking as viterbi_compact_kernel.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void viterbi_fs_init_kernel(const ViterbiArgs a, int n_utts)
+{
+    const int slot = blockIdx.y;
+    const int ninf = __float_as_int(-1e20f);
+    i32x4* pp = (i32x4*)a.pp + (size_t)slot * a.T;
+    int* t2 = a.tt + (size_t)slot * a.T;
+    float* p = a.p + (size_t)slot * a.B;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.T; i += gridDim.x * 256) { pp[i] = (i32x4){ninf, ninf, ninf, 1 | (1 << 16)}; t2[i] = 1; }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.B; i += gridDim.x * 256) p[i] = a.p0[i];
+}
+
+__global__ __launch_bounds__(256) void viterbi_fs_tri_kernel(const ViterbiArgs a, int k)
+{
+    const int slot = blockIdx.y;
+    const int T = a.T;
+    const int n = blockIdx.x * 512 + threadIdx.x;          // this thread: triphones n and n + 256
+    if (n >= T) return;
+    const long long row0 = a.offsets[a.slot_utt[slot]];
+    i32x4* pp = (i32x4*)a.pp + (size_t)slot * T;
+    int* t2 = a.tt + (size_t)slot * T;
+    float* pout = a.pout + (size_t)slot * T;
+    const float* p = a.p + (size_t)slot * a.B;
+    const float* lp1 = a.lp + (size_t)(row0 + k) * a.ldl;
+    const i32x4* c0 = (const i32x4*)a.tri_idx;
+    const f32x4* c1 = (const f32x4*)a.tri_self;
+    const bool two = n + 256 < T;
+    const int m = two ? n + 256 : n;
+    const i32x4 ga = c0[n], gb = c0[m];
+    const f32x4 ha = c1[n], hb = c1[m];
+    const i32x4 qa = pp[n], qb = pp[m];
+    const int ta = t2[n], tb = t2[m];
+    i32x4 nqa, nqb; int nta, ntb; float poa, pob;
+    viterbi_tri_update(ga, ha, qa, ta, p, lp1, a.PIP, k, nqa, nta, poa);
+    viterbi_tri_update(gb, hb, qb, tb, p, lp1, a.PIP, k, nqb, ntb, pob);
+    pp[n] = nqa; t2[n] = nta; pout[n] = poa;
+    if (two) { pp[m] = nqb; t2[m] = ntb; pout[m] = pob; }
+}
+
+// one wave per node: lanes stride over the arriving triphones; the reference takes the FIRST strict maximum in list order
+// (phone_recog.cpp:190-200), i.e. the largest exit score and, among equals, the smallest list position
+__global__ __launch_bounds__(256) void viterbi_fs_node_kernel(const ViterbiArgs a, int k)
+{
+    const int slot = blockIdx.y;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.B) return;
+    const int lane = threadIdx.x & 63;
+    const float* pout = a.pout + (size_t)slot * a.T;
+    const int s0 = a.outOff[i], s1 = a.outOff[i + 1];
+    float mx = -1e20f; int ms = 0x7fffffff, mxi = 0;
+    for (int s = s0 + lane; s < s1; s += 64) {
+        const int ids = a.outVal[s];
+        const float pOut = pout[ids];
+        if (mx < pOut) { mx = pOut; ms = s; mxi = ids; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float omx = __shfl_xor(mx, off);
+        const int oms = __shfl_xor(ms, off), omi = __shfl_xor(mxi, off);
+        if (omx > mx || (omx == mx && oms < ms)) { mx = omx; ms = oms; mxi = omi; }
+    }
+    if (lane == 0) {
+        if (ms == 0x7fffffff) mxi = 0;                     // nothing exceeded -1e20: the reference keeps index 0
+        const long long row = a.offsets[a.slot_utt[slot]] + k;
+        a.p[(size_t)slot * a.B + i] = mx + a.lm[i];
+        a.bestI[(size_t)row * a.B + i] = mxi;
+        a.bestT[(size_t)row * a.B + i] = a.tt[(size_t)slot * a.T + mxi] - 1;
+    }
+}
+
+__global__ __launch_bounds__(64) void viterbi_fs_trace_kernel(const ViterbiArgs a, int n_utts)
+{
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    if (slot >= n_utts) return;
+    const int u = a.slot_utt[slot];
+    const long long row0 = a.offsets[u];
+    const int N = (int)(a.offsets[u + 1] - row0), B = a.B;
+    const float* p = a.p + (size_t)slot * B;
+    const int* bI = a.bestI + (size_t)row0 * B;
+    const int* bT = a.bestT + (size_t)row0 * B;
+    const i32x4* c0 = (const i32x4*)a.tri_idx;
+    int mxi = 0;
+    float mx = -1e20f;
+    for (int i = 0; i < a.P; ++i) {
+        const int ids = a.endIdx[i];
+        if (mx < p[ids]) { mx = p[ids]; mxi = ids; }
+    }
+    int count = 0, t = N - 1;
+    bool ok = true;
+    while (t >= 0) {
+        if (count >= N) { ok = false; break; }           // the reference would loop forever here
+        const int id = bI[(size_t)t * B + mxi];
+        const int end = t + 1;
+        t = bT[(size_t)t * B + mxi];
+        a.seg_end[row0 + count] = end;
+        a.seg_begin[row0 + count] = t + 1;
+        a.seg_tri[row0 + count] = id;
+        mxi = c0[id][0] & 0xffff;
+        ++count;
+    }
+    a.seg_count[u] = ok ? count : 0;
+}
+
+hipError_t launch_viterbi_fs_init(hipStream_t s, const ViterbiArgs& a, int n_utts)
+{
+    if (n_utts <= 0) return hipSuccess;
+    hipLaunchKernelGGL(viterbi_fs_init_kernel, dim3(32, n_utts), dim3(256), 0, s, a, n_utts);
+    return hipGetLastError();
+}
+
+hipError_t launch_viterbi_fs_step(hipStream_t s, const ViterbiArgs& a, int k, int n_active)
+{
+    if (n_active <= 0) return hipSuccess;
+    hipLaunchKernelGGL(viterbi_fs_tri_kernel, dim3((a.T + 511) / 512, n_active), dim3(256), 0, s, a, k);
+    hipLaunchKernelGGL(viterbi_fs_node_kernel, dim3((a.B + 3) / 4, n_active), dim3(256), 0, s, a, k);
+    return hipGetLastError();
+}
+
+hipError_t launch_viterbi_fs_trace(hipStream_t s, const ViterbiArgs& a, int n_utts)
+{
+    if (n_utts <= 0) return hipSuccess;
+    hipLaunchKernelGGL(viterbi_fs_trace_kernel, dim3((n_utts + 63) / 64), dim3(64), 0, s, a, n_utts);
+    return hipGetLastError();
+}
+
 hipError_t launch_viterbi(hipStream_t s, const ViterbiArgs& a, int n_utts)
 {
     if (n_utts <= 0) return hipSuccess;

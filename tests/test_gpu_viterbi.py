@@ -58,6 +58,54 @@ def test_larger_graphs_match_oracle(engine, P, S, PIP):
     dec.close()
 
 
+def test_decoder_forms_agree_in_fresh_processes():
+    """Three kernels implement the decoder: frame-synchronous (default), one workgroup per utterance with compact records
+    (AM_VITERBI_FS=0) and with 32-bit records (AM_VITERBI_COMPACT=0; what graphs with >= 65,536 nodes or columns get).  The
+    choice is read once per process, so each runs in its own; all must give the default form's segmentations, incl. ties."""
+    import subprocess
+    import sys
+    import tempfile
+    code = r"""
+import os, sys, json, numpy as np
+sys.path.insert(0, os.getcwd())
+from oracle import viterbi_oracle as vo
+from nnacousticmodeling_amd.engine import Engine
+from nnacousticmodeling_amd.phone_recog import PhoneRecog
+rng = np.random.default_rng(77)
+graph = vo.make_graph(rng, 11, 400)
+lens = [3, 57, 120, 4, 33, 250, 2, 19]
+z = np.round(3.0 * rng.standard_normal((sum(lens), 400)), 1)          # coarse values: plenty of exact ties
+lp = (z - np.log(np.sum(np.exp(z), axis=1, keepdims=True))).astype(np.float32)
+off = np.concatenate([[0], np.cumsum(lens)])
+dec = PhoneRecog(Engine(0), dict(graph, numPhones=11, numBiphones=len(graph["lm"]), numTriphones=len(graph["biphoneIdxIn"])), -2.0, 0.9)
+json.dump(dec.recognise(lp, off), open(sys.argv[1], "w"))
+"""
+    outs = []
+    for env in ({}, {"AM_VITERBI_FS": "0"}, {"AM_VITERBI_COMPACT": "0"}):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "segs.json")
+            res = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300,
+                                 cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            assert res.returncode == 0, res.stderr[-2000:]
+            outs.append(open(out).read())
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 100
+    # and the oracle's (first strict maximum wins, phone_recog.cpp:190-200) on the same tie-heavy input
+    import json
+    rng = np.random.default_rng(77)
+    graph = vo.make_graph(rng, 11, 400)
+    lens = [3, 57, 120, 4, 33, 250, 2, 19]
+    z = np.round(3.0 * rng.standard_normal((sum(lens), 400)), 1)
+    lp = (z - np.log(np.sum(np.exp(z), axis=1, keepdims=True))).astype(np.float32)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    got = json.loads(outs[0])
+    for u, n in enumerate(lens):
+        if n >= 3:
+            want = [[b, e, graph["phones"][t]] for b, e, t in vo.recog_one(graph, lp[off[u]:off[u + 1]], -2.0, 0.9)]
+            assert got[u] == want, u
+        else:
+            assert got[u] == []
+
+
 def test_evaluate_end_to_end_with_gpu_decoder(engine, tmp_path, real_ft_path, real_priors):
     """evaluate CLI on a synthetic 1909-state graph: posteriors -> in-process GPU Viterbi -> 60->39 map -> NIST PER."""
     from nnacousticmodeling_amd import chainer_npz, evaluate, scoring
