@@ -1485,6 +1485,7 @@ struct am_decoder {
     DevBuf d_slot;       // frame-synchronous form: slot -> utterance
     DevBuf cmp0, cmp1;   // compact 32-B graph records (nodes and posterior columns < 65536), see viterbi_compact_kernel
     bool has_compact = false;
+    int perm = 0, inv0 = 0;   // compact records stored in arrival-list order (see ViterbiArgs::perm)
     DevBuf d_lp, d_off, pp, tt, pout, p, bestI, bestT, seg_begin, seg_end, seg_tri, seg_count;
 };
 
@@ -1540,15 +1541,27 @@ extern "C" int am_decoder_create(am_engine* e, int numPhones, int numBiphones, i
     }
     int rc = AM_OK;
     if (B < 65536 && numStates < 65536) {
+        // when every triphone arrives at exactly one node (the arrival lists are a permutation of the triphones, as in a
+        // triphone loop), store everything in arrival-list order: the node maxima then read contiguous exit scores
+        std::vector<int> order(T);
+        bool is_perm = outOffsets[B] == T;
+        if (is_perm) {
+            std::vector<char> seen(T, 0);
+            for (int s3 = 0; s3 < T && is_perm; ++s3) { if (seen[outValues[s3]]) is_perm = false; seen[outValues[s3]] = 1; }
+        }
+        for (int s3 = 0; s3 < T; ++s3) order[s3] = is_perm ? outValues[s3] : s3;
+        d->perm = is_perm;
+        for (int s3 = 0; s3 < T; ++s3) if (order[s3] == 0) d->inv0 = s3;
         std::vector<int> c0(4 * (size_t)T);
         std::vector<float> c1(4 * (size_t)T);
-        for (int n = 0; n < T; ++n) {
-            c0[4 * n] = biphoneIdxIn[n] | (stateIdxs[3 * n] << 16);
-            c0[4 * n + 1] = stateIdxs[3 * n + 1] | (stateIdxs[3 * n + 2] << 16);
-            memcpy(&c0[4 * n + 2], &tpSelfloop[3 * n], sizeof(float));
-            memcpy(&c0[4 * n + 3], &tpSelfloop[3 * n + 1], sizeof(float));
-            c1[4 * n] = tpSelfloop[3 * n + 2];
-            c1[4 * n + 1] = tpTransition[3 * n]; c1[4 * n + 2] = tpTransition[3 * n + 1]; c1[4 * n + 3] = tpTransition[3 * n + 2];
+        for (int m2 = 0; m2 < T; ++m2) {
+            const int n = order[m2];
+            c0[4 * m2] = biphoneIdxIn[n] | (stateIdxs[3 * n] << 16);
+            c0[4 * m2 + 1] = stateIdxs[3 * n + 1] | (stateIdxs[3 * n + 2] << 16);
+            memcpy(&c0[4 * m2 + 2], &tpSelfloop[3 * n], sizeof(float));
+            memcpy(&c0[4 * m2 + 3], &tpSelfloop[3 * n + 1], sizeof(float));
+            c1[4 * m2] = tpSelfloop[3 * n + 2];
+            c1[4 * m2 + 1] = tpTransition[3 * n]; c1[4 * m2 + 2] = tpTransition[3 * n + 1]; c1[4 * m2 + 3] = tpTransition[3 * n + 2];
         }
         if ((rc = upload_raw(e, d->cmp0, c0.data(), c0.size())) != AM_OK || (rc = upload_raw(e, d->cmp1, c1.data(), c1.size())) != AM_OK) {
             am_decoder_destroy(d);
@@ -1609,7 +1622,7 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
     for (int u = 0; u < n_utts; ++u) longest = std::max(longest, offsets[u + 1] - offsets[u]);
     static const int64_t compact_ok = env_int("AM_VITERBI_COMPACT", 1);
     if (d->has_compact && longest < 65535 && compact_ok) {   // entry times travel as 16-bit (t + 1)
-        a.compact = 1;
+        a.compact = 1; a.perm = d->perm; a.inv0 = d->inv0;
         a.tri_idx = (decltype(a.tri_idx))d->cmp0.p; a.tri_self = (decltype(a.tri_self))d->cmp1.p;
     }
     a.outOff = d->outOff.as<int>(); a.outVal = d->outVal.as<int>();

@@ -140,6 +140,8 @@ hipError_t launch_rec_step(hipStream_t s, int epilogue, const RecStepArgs& a);
 struct ViterbiArgs {
     int P, B, T;                       // phones (start/end nodes), biphone nodes, triphones
     int compact;                       // 1: the records are in the compact layout of viterbi_compact_kernel (tri_idx = c0, tri_self = c1)
+    int perm, inv0;                    // perm = 1: the compact records (and all per-triphone state) are stored in arrival-list order, internal
+                                       // index s <-> reference triphone outVal[s]; inv0 = internal index of the reference's triphone 0
     const int* endIdx;                 // [P]
     // one 16-B record per triphone n (packed at load for coalesced access):
     const __attribute__((ext_vector_type(4))) int* tri_idx;     // {node it leaves from, posterior column of state 0, 1, 2}

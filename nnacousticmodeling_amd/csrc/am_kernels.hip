@@ -1616,10 +1616,10 @@ __global__ __launch_bounds__(1024) void viterbi_compact_kernel(const ViterbiArgs
         }
         __syncthreads();
         for (int i = tid; i < B; i += 1024) {
-            int mxi = 0;
+            int mxi = a.perm ? a.inv0 : 0;                  // internal index of the reference's triphone 0
             float mx = NINF;
             for (int s = a.outOff[i]; s < a.outOff[i + 1]; ++s) {
-                const int ids = a.outVal[s];
+                const int ids = a.perm ? s : a.outVal[s];   // perm: triphones are stored in arrival-list order
                 const float pOut = pout[ids];
                 if (mx < pOut) { mx = pOut; mxi = ids; }
             }
@@ -1645,7 +1645,7 @@ __global__ __launch_bounds__(1024) void viterbi_compact_kernel(const ViterbiArgs
             t = bT[(size_t)t * B + mxi];
             a.seg_end[row0 + count] = end;
             a.seg_begin[row0 + count] = t + 1;
-            a.seg_tri[row0 + count] = id;
+            a.seg_tri[row0 + count] = a.perm ? a.outVal[id] : id;   // back to the reference's numbering
             mxi = c0[id][0] & 0xffff;
             ++count;
         }
@@ -1698,30 +1698,43 @@ __global__ __launch_bounds__(256) void viterbi_fs_tri_kernel(const ViterbiArgs a
     if (two) { pp[m] = nqb; t2[m] = ntb; pout[m] = pob; }
 }
 
-// one wave per node: lanes stride over the arriving triphones; the reference takes the FIRST strict maximum in list order
-// (phone_recog.cpp:190-200), i.e. the largest exit score and, among equals, the smallest list position
+// 8 lanes per node (8 nodes per wave, 32 per block): a lane takes arrivals s0 + l, s0 + l + 8, ...; the first 8 trips are
+// unrolled so their loads fly together (a list of <= 64 arrivals costs one round trip; one WAVE per node was latency-bound:
+// 442 k waves per launch at 192 utterances, as long as the triphone kernel).  The reference takes the FIRST strict maximum
+// in list order (phone_recog.cpp:190-200), i.e. the largest exit score and, among equals, the smallest list position.
 __global__ __launch_bounds__(256) void viterbi_fs_node_kernel(const ViterbiArgs a, int k)
 {
     const int slot = blockIdx.y;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= a.B) return;
-    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int l8 = threadIdx.x & 7;
+    const bool valid = i < a.B;
     const float* pout = a.pout + (size_t)slot * a.T;
-    const int s0 = a.outOff[i], s1 = a.outOff[i + 1];
+    const int s0 = valid ? a.outOff[i] : 0, s1 = valid ? a.outOff[i + 1] : 0;
     float mx = -1e20f; int ms = 0x7fffffff, mxi = 0;
-    for (int s = s0 + lane; s < s1; s += 64) {
-        const int ids = a.outVal[s];
+    float v[8]; int id[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int s = s0 + l8 + 8 * j;
+        id[j] = s < s1 ? (a.perm ? s : a.outVal[s]) : -1;   // perm: triphones stored in arrival-list order -> contiguous reads
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = id[j] >= 0 ? pout[id[j]] : -1e20f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (id[j] >= 0 && mx < v[j]) { mx = v[j]; ms = s0 + l8 + 8 * j; mxi = id[j]; }
+    for (int s = s0 + l8 + 64; s < s1; s += 8) {
+        const int ids = a.perm ? s : a.outVal[s];
         const float pOut = pout[ids];
         if (mx < pOut) { mx = pOut; ms = s; mxi = ids; }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+    for (int off = 4; off > 0; off >>= 1) {
         const float omx = __shfl_xor(mx, off);
         const int oms = __shfl_xor(ms, off), omi = __shfl_xor(mxi, off);
         if (omx > mx || (omx == mx && oms < ms)) { mx = omx; ms = oms; mxi = omi; }
     }
-    if (lane == 0) {
-        if (ms == 0x7fffffff) mxi = 0;                     // nothing exceeded -1e20: the reference keeps index 0
+    if (valid && l8 == 0) {
+        if (ms == 0x7fffffff) mxi = a.perm ? a.inv0 : 0;   // nothing exceeded -1e20: the reference keeps its triphone 0
         const long long row = a.offsets[a.slot_utt[slot]] + k;
         a.p[(size_t)slot * a.B + i] = mx + a.lm[i];
         a.bestI[(size_t)row * a.B + i] = mxi;
@@ -1755,7 +1768,7 @@ __global__ __launch_bounds__(64) void viterbi_fs_trace_kernel(const ViterbiArgs 
         t = bT[(size_t)t * B + mxi];
         a.seg_end[row0 + count] = end;
         a.seg_begin[row0 + count] = t + 1;
-        a.seg_tri[row0 + count] = id;
+        a.seg_tri[row0 + count] = a.perm ? a.outVal[id] : id;
         mxi = c0[id][0] & 0xffff;
         ++count;
     }
@@ -1773,7 +1786,7 @@ hipError_t launch_viterbi_fs_step(hipStream_t s, const ViterbiArgs& a, int k, in
 {
     if (n_active <= 0) return hipSuccess;
     hipLaunchKernelGGL(viterbi_fs_tri_kernel, dim3((a.T + 511) / 512, n_active), dim3(256), 0, s, a, k);
-    hipLaunchKernelGGL(viterbi_fs_node_kernel, dim3((a.B + 3) / 4, n_active), dim3(256), 0, s, a, k);
+    hipLaunchKernelGGL(viterbi_fs_node_kernel, dim3((a.B + 31) / 32, n_active), dim3(256), 0, s, a, k);
     return hipGetLastError();
 }
 

@@ -58,6 +58,31 @@ def test_larger_graphs_match_oracle(engine, P, S, PIP):
     dec.close()
 
 
+def test_arrival_lists_that_are_not_a_permutation(engine):
+    """The decoder stores its state in arrival-list order when every triphone arrives at exactly one node; a graph where one
+    triphone arrives nowhere and another at two nodes must take the general (gather) form and still match the oracle."""
+    from nnacousticmodeling_amd.phone_recog import PhoneRecog
+    rng = np.random.default_rng(5)
+    P, S = 7, 90
+    graph = vo.make_graph(rng, P, S)
+    off, val = np.array(graph["outOffsets"]), np.array(graph["outValues"])
+    node = int(np.argmax(np.diff(off) >= 2))
+    val[off[node]] = val[off[node + 1]]          # first arrival of `node` replaced by one that also arrives at the next node
+    # and one node with a long list (> 64 arrivals: the node kernel's unrolled trips plus its tail loop)
+    lists = [list(val[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+    lists[node + 1] += [int(t) for t in rng.integers(0, len(graph["biphoneIdxIn"]), 150)]
+    off = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int32)
+    val = np.array([t for l in lists for t in l], dtype=np.int32)
+    graph = dict(graph, outOffsets=off, outValues=val)
+    lens = [30, 75, 12]
+    lps = [_logsoftmax(3.0 * rng.standard_normal((n, S))) for n in lens]
+    dec = PhoneRecog(engine, dict(graph, numPhones=P, numBiphones=len(graph["lm"]), numTriphones=len(graph["biphoneIdxIn"])), -1.5, 0.8)
+    got = dec.recognise(np.concatenate(lps), np.concatenate([[0], np.cumsum(lens)]))
+    for lp, segs in zip(lps, got):
+        assert segs == [(b, e, graph["phones"][t]) for b, e, t in vo.recog_one(graph, lp, -1.5, 0.8)]
+    dec.close()
+
+
 def test_decoder_forms_agree_in_fresh_processes():
     """Three kernels implement the decoder: frame-synchronous (default), one workgroup per utterance with compact records
     (AM_VITERBI_FS=0) and with 32-bit records (AM_VITERBI_COMPACT=0; what graphs with >= 65,536 nodes or columns get).  The
