@@ -140,6 +140,8 @@ class Model:
     ``params``: Chainer npz keys without the ``predictor/`` prefix:
     ff   -> layer_{l}/W [units,in], layer_{l}/b, out/W [C,units], out/b
     lstm -> layer_{l}/upward/W [4U,in], layer_{l}/upward/b [4U], layer_{l}/lateral/W [4U,U], out/W, out/b
+    tdnn -> layer_{l}/W [units_l, in_l, 1, k_l], layer_{l}/b, out/W, out/b
+    gru / mgrurelu / mgrurelur / peepholelstm -> the keys listed in ``networks.RNN_CELLS`` + out/W, out/b
     Layer input sizes are taken from the stored shapes, as ``L.Linear(None, ...)`` does.
     """
 
@@ -170,7 +172,7 @@ class Model:
             self._create_tdnn(engine, params, ACTIVATIONS[activation])
             return
         else:
-            raise ValueError("network %r is not supported by the MI355X engine (supported: ff, lstm, %s)" % (network, ", ".join(RNN_CELLS)))
+            raise ValueError("network %r is not supported by the MI355X engine (supported: ff, tdnn, lstm, %s)" % (network, ", ".join(RNN_CELLS)))
         ws.append(_f32(params["out/W"]))
         bs.append(_f32(params["out/b"]))
         n = self.layers + 1

@@ -147,7 +147,7 @@ class RPL4Spec:
 
 def get_nn(network, layers, units, num_classes, activation="relu", tdnn_ksize=None, dropout=(0,)):
     """Same argument order as the reference ``get_nn``.  ``activation`` is a name (relu/sigmoid/tanh); dropout is
-    accepted and ignored (identity at inference, evaluate.py:94).  Networks outside the hot-path scope are refused."""
+    accepted and ignored (identity at inference, evaluate.py:94).  Every network of the reference's get_nn is built."""
     if network in SUPPORTED:
         if activation not in ("relu", "sigmoid", "tanh"):
             raise ValueError("Wrong activation function specified")
