@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU (not part of the test-suite): random network kinds, widths, depths, window sizes,
+utterance mixes and epilogues against the CPU oracle, 1e-4 max-abs.  usage: tools/fuzz_gpu.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nnacousticmodeling_amd.engine import Engine, Model, Pipeline  # noqa: E402
+from oracle import am_oracle as orc  # noqa: E402
+
+TOL = 1e-4
+
+
+def one(eng, rng, ft_full, it):
+    kind = rng.choice(["ff", "tdnn", "lstm", "gru", "mgrurelu", "mgrurelur", "peepholelstm"])
+    D = int(rng.choice([40, 40, 24, 13]))
+    C = int(rng.choice([1909, 39, 257, 600]))
+    prior = (0.3 * rng.standard_normal(C)).astype(np.float32) if rng.random() < 0.5 else None
+    desc = {"it": it, "kind": kind, "D": D, "C": C, "prior": prior is not None}
+    p = Pipeline(eng)
+    if kind in ("ff", "tdnn"):
+        n = int(rng.choice([1, 2, 63, 255, 256, 257, 1000, 3001]))
+        x = rng.standard_normal((n, D)).astype(np.float32)
+        if kind == "ff":
+            s = int(rng.choice([0, 1, 5]))
+            layers, units = int(rng.integers(0, 5)), int(rng.choice([8, 64, 100, 256, 300, 1024]))
+            act = str(rng.choice(["relu", "sigmoid", "tanh"]))
+            shifts = list(range(-s, s + 1))
+            add = (0.1 * rng.standard_normal(len(shifts) * D)).astype(np.float32)
+            scale = rng.uniform(0.5, 1.5, len(shifts) * D).astype(np.float32)
+            ft = {"shape": [len(shifts) * D, D], "shifts": shifts, "addShift": add, "rescale": scale}
+            d_iv = int(rng.choice([0, 0, 4, 100]))
+            iv = rng.standard_normal((n, d_iv)).astype(np.float32) if d_iv else None
+            params = orc.make_mlp_params(rng, len(shifts) * D + d_iv, units, layers, C)
+            net = orc.MLP(params, layers, act)
+            desc.update(n=n, splice=s, layers=layers, units=units, act=act, d_iv=d_iv)
+            data = orc.evaluate_frontend(x, s, ft, iv)
+            want = np.concatenate(orc.evaluate_posteriors(net, data, np.array([0, n]), ap=None if prior is None else prior.reshape(1, -1)))
+            p.set_frontend(D, shifts, add, scale, d_iv)
+            p.set_members([Model(eng, "ff", layers, params, act)])
+            p.set_prior(prior)
+            got = p.forward_ff(x, iv)
+        else:
+            nl = int(rng.integers(1, 4))
+            ksize = [int(k) for k in rng.choice([1, 3, 5, 7], nl)]
+            if (sum(ksize) - nl) % 2:
+                ksize[0] += 2 if ksize[0] == 1 else -2 if ksize[0] > 3 else 2
+                if (sum(ksize) - nl) % 2:
+                    ksize[0] = 3
+            while (sum(ksize) - nl) % 2:
+                ksize.append(2); nl += 1
+            units = [int(u) for u in rng.choice([8, 40, 64, 200, 256], nl)]
+            act = str(rng.choice(["relu", "sigmoid", "tanh"]))
+            s = (sum(ksize) - nl) // 2
+            shifts = list(range(-s, s + 1))
+            add = (0.1 * rng.standard_normal(len(shifts) * D)).astype(np.float32)
+            scale = rng.uniform(0.5, 1.5, len(shifts) * D).astype(np.float32)
+            ft = {"shape": [len(shifts) * D, D], "shifts": shifts, "addShift": add, "rescale": scale}
+            params = orc.make_tdnn_params(rng, D, units, ksize, C)
+            desc.update(n=n, ksize=ksize, units=units, act=act)
+            data = orc.evaluate_frontend(x, s, ft)
+            want = np.concatenate(orc.evaluate_posteriors(orc.TDNN(params, nl, act), data, np.array([0, n]), ap=None if prior is None else prior.reshape(1, -1)))
+            p.set_frontend(D, shifts, add, scale, 0)
+            p.set_members([Model(eng, "tdnn", nl, params, act)])
+            p.set_prior(prior)
+            got = p.forward_ff(x)
+    else:
+        n_utts = int(rng.choice([1, 3, 17, 33, 70]))
+        lens = rng.integers(1, 60, n_utts)
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        n = int(offsets[-1])
+        x = rng.standard_normal((n, D)).astype(np.float32)
+        layers, units = int(rng.integers(1, 4)), int(rng.choice([8, 64, 96, 128, 200, 256, 512]))
+        td = int(rng.choice([0, 0, 2, 5]))
+        add = (0.1 * rng.standard_normal(D)).astype(np.float32)
+        scale = rng.uniform(0.5, 1.5, D).astype(np.float32)
+        ft = {"shape": [D, D], "shifts": [0], "addShift": add, "rescale": scale}
+        if kind in ("lstm", "peepholelstm"):
+            params = (orc.make_peephole_params if kind == "peepholelstm" else orc.make_lstm_params)(rng, D, units, layers, C)
+        else:
+            params = orc.make_gru_params(rng, D, units, layers, C, reset_gate=kind != "mgrurelu")
+        desc.update(n=n, n_utts=n_utts, layers=layers, units=units, timedelay=td)
+        if prior is None:
+            want = orc.predict(orc.get_nn(kind, layers, params), x, offsets, True, 1, td, ft)
+        else:
+            td = 0
+            want = np.concatenate(orc.evaluate_posteriors(orc.get_nn(kind, layers, params), orc.evaluate_frontend(x, 0, ft), offsets, ap=prior.reshape(1, -1), rnn=True))
+        p.set_frontend(D, [0], add, scale, 0)
+        p.set_members([Model(eng, kind, layers, params)])
+        p.set_prior(prior)
+        got = p.forward_lstm(x, offsets, timedelay=td)
+    err = float(np.max(np.abs(got - want))) if got.size else 0.0
+    p.close()
+    if not (err <= TOL) and kind not in ("ff", "tdnn"):
+        # random recurrent nets with unbounded activations (mgrurelu) can be unstable: |y| reaches 1e6 and the float32 and float64
+        # ORACLES then disagree by more than 1e-4 themselves; such a case says nothing about the device path
+        w64 = orc.predict(orc.get_nn(kind, layers, params, dtype=np.float64), x, offsets, True, 1, td, ft) if prior is None else \
+            np.concatenate(orc.evaluate_posteriors(orc.get_nn(kind, layers, params, dtype=np.float64), orc.evaluate_frontend(x, 0, ft), offsets, ap=prior.reshape(1, -1), rnn=True))
+        spread = float(np.max(np.abs(want - w64)))
+        desc.update(oracle_f32_vs_f64=spread, max_abs=float(np.max(np.abs(want))))
+        if err <= 4.0 * spread:
+            desc["ill_conditioned"] = True
+            return 0.0, desc
+    return err, desc
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    eng = Engine(0)
+    t0, it, worst, fails = time.time(), 0, (0.0, None), 0
+    while time.time() - t0 < budget:
+        err, desc = one(eng, rng, None, it)
+        if not (err <= TOL):
+            fails += 1
+            print("FAIL", err, desc, flush=True)
+        if err > worst[0]:
+            worst = (err, desc)
+        it += 1
+    print("iterations", it, "failures", fails, "worst", worst, flush=True)
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
