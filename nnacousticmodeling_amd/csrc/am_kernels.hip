@@ -877,8 +877,8 @@ __global__ __launch_bounds__(512, 4) void lstm_wavefront_kernel(const LstmWavefr
 // ---------------------------------------------------------------------------------------------------
 constexpr int LSTM_WREG_ROWS = 96;        // row capacity of the LDS tiles (6 row tiles)
 constexpr size_t LSTM_WREG_LDS = 2 * LSTM_WREG_ROWS * LSTM_LDA * sizeof(float);   // 101,376 B; the gate exchange buffer aliases it after the K loop
-constexpr int LSTM_WREG_PAIR_ROWS = 48;   // two-blocks-per-CU form: 3 row tiles
-constexpr size_t LSTM_WREG_PAIR_LDS = 2 * LSTM_WREG_PAIR_ROWS * LSTM_LDA * sizeof(float);   // 50,688 B
+constexpr int LSTM_WREG_PAIR_ROWS = 32;   // two-blocks-per-CU form: 2 row tiles
+constexpr size_t LSTM_WREG_PAIR_LDS = 2 * LSTM_WREG_PAIR_ROWS * LSTM_LDA * sizeof(float);   // 33,792 B
 
 template <int NT, int D>
 __device__ __forceinline__ void lstm_wreg_body(const LstmLayerStep& Ls, int U_pad, int ut, int row0, float* smem, int tile_rows)
@@ -1001,7 +1001,7 @@ __device__ __forceinline__ void lstm_wreg_body(const LstmLayerStep& Ls, int U_pa
 
 // PAIR = false: one block per CU (up to 256 VGPRs), 1..6 row tiles, 4 weight batches in flight (2 at 6 tiles: 2.6 us of
 // MFMA per batch already covers a round trip, 4 would spill).  PAIR = true: two co-resident blocks per CU (128 VGPRs),
-// 1..3 row tiles, 2 batches in flight: one block's barrier bubbles are filled by the other's MFMAs.
+// 1..2 row tiles, 2 batches in flight: one block's barrier bubbles are filled by the other's MFMAs.
 template <bool PAIR>
 __global__ __launch_bounds__(512, PAIR ? 4 : 2) void lstm_wreg_kernel(const LstmWavefrontArgs args)
 {
@@ -1022,7 +1022,6 @@ __global__ __launch_bounds__(512, PAIR ? 4 : 2) void lstm_wreg_kernel(const Lstm
         switch (ntile) {   // uniform per block
         case 1: lstm_wreg_body<1, 2>(Ls, U_pad, ut, row0, wreg_smem, LSTM_WREG_PAIR_ROWS); break;
         case 2: lstm_wreg_body<2, 2>(Ls, U_pad, ut, row0, wreg_smem, LSTM_WREG_PAIR_ROWS); break;
-        case 3: lstm_wreg_body<3, 2>(Ls, U_pad, ut, row0, wreg_smem, LSTM_WREG_PAIR_ROWS); break;
         default: break;
         }
     } else {
@@ -1224,7 +1223,7 @@ hipError_t launch_lstm_wavefront(hipStream_t s, LstmWavefrontArgs& a)
         const int pair_mode = lstm_wreg_mode();   // 1: choose by the cost model, 2: never pair, 3: always pair (A/B measurements)
         for (int pair = 0; pair < 2; ++pair) {
             if ((pair && pair_mode == 2) || (!pair && pair_mode == 3)) continue;
-            const int tmax = pair ? 3 : 6;
+            const int tmax = pair ? 2 : 6;   // a 3-tile instantiation of the 128-VGPR form spills
             for (int cf = tmax; cf >= 1; --cf)
                 for (int cp = tmax; cp >= 1; --cp) {
                     int blocks = 0; float work = 0.0f; bool any_part = false, any_full = false;
