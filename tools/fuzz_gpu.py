@@ -15,7 +15,64 @@ from oracle import am_oracle as orc  # noqa: E402
 TOL = 1e-4
 
 
+def ensemble_case(eng, rng, it):
+    """NNWithRPL combinations (evaluate.py:35-51) and the dev-mode log-posterior mean (predict_folds.py:199-220), feed-forward
+    or mixed recurrent members, optionally in the split-f16 precision mode (feed-forward)."""
+    from nnacousticmodeling_amd._lib import AM_COMBINE_LOGITS, AM_COMBINE_LOGPOST
+    D, C = 40, int(rng.choice([1909, 100]))
+    K = int(rng.integers(1, 5))
+    recurrent = rng.random() < 0.4
+    master = rng.random() < 0.5
+    dev = (not master) and rng.random() < 0.4
+    rpl = (not dev) and rng.random() < 0.5
+    split = (not recurrent) and rng.random() < 0.4
+    desc = {"it": it, "kind": "ensemble", "recurrent": recurrent, "K": K, "master": master, "dev": dev, "rpl": rpl, "split": split, "C": C}
+    add = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, D).astype(np.float32)
+    ft = {"shape": [D, D], "shifts": [0], "addShift": add, "rescale": scale}
+    n_members = K + (1 if master else 0)
+    p = Pipeline(eng)
+    if recurrent:
+        kinds = [str(rng.choice(["lstm", "gru", "peepholelstm"])) for _ in range(n_members)]
+        lens = rng.integers(1, 40, int(rng.choice([2, 9, 20])))
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        n = int(offsets[-1])
+        plist = [(orc.make_lstm_params if k == "lstm" else orc.make_peephole_params if k == "peepholelstm" else orc.make_gru_params)(rng, D, 64, 1, C) for k in kinds]
+        nets = [orc.get_nn(k, 1, q) for k, q in zip(kinds, plist)]
+        models = [Model(eng, k, 1, q) for k, q in zip(kinds, plist)]
+        desc["kinds"] = kinds
+    else:
+        offsets = None
+        n = int(rng.choice([5, 300, 1100]))
+        units = int(rng.choice([64, 256]))
+        plist = [orc.make_mlp_params(rng, D, units, 2, C) for _ in range(n_members)]
+        nets = [orc.MLP(q, 2) for q in plist]
+        models = [Model(eng, "ff", 2, q) for q in plist]
+    x = rng.standard_normal((n, D)).astype(np.float32)
+    rplp = {"W": 0.05 * rng.standard_normal((1, C)).astype(np.float32), "b": 0.1 * rng.standard_normal((1, C)).astype(np.float32),
+            "lb": np.full((1, C), -20, np.float32)} if rpl else None
+    if dev:
+        want = orc.fold_average_dev(nets, x, offsets, recurrent, 1, 0, ft)
+    else:
+        omodel = orc.NNWithRPL(nets[0] if master else None, nets[1:] if master else nets, orc.RPL4(rplp) if rpl else None)
+        want = orc.predict(omodel, x, offsets, recurrent, 1, 0, ft)
+    p.set_frontend(D, [0], add, scale, 0)
+    p.set_members(models, has_master=master, combine=AM_COMBINE_LOGPOST if dev else AM_COMBINE_LOGITS)
+    if rpl:
+        p.set_rpl4(rplp["W"], rplp["b"], rplp["lb"])
+    try:
+        if split:
+            eng.set_precision("split_f16")
+        got = p.forward_lstm(x, offsets) if recurrent else p.forward_ff(x)
+    finally:
+        eng.set_precision("f32")
+    p.close()
+    return (float(np.max(np.abs(got - want))) if got.size else 0.0), desc
+
+
 def one(eng, rng, ft_full, it):
+    if rng.random() < 0.2:
+        return ensemble_case(eng, rng, it)
     kind = rng.choice(["ff", "tdnn", "lstm", "gru", "mgrurelu", "mgrurelur", "peepholelstm"])
     D = int(rng.choice([40, 40, 24, 13]))
     C = int(rng.choice([1909, 39, 257, 600]))
