@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep on the GPU (not part of the test-suite): random network kinds, widths, depths, window sizes,
-utterance mixes and epilogues against the CPU oracle, 1e-4 max-abs.  usage: tools/fuzz_gpu.py [seconds] [seed]"""
+"""Randomised parity sweep on the GPU (a checker kept beside the tests, not collected by pytest): random network kinds, widths, depths, window sizes,
+utterance mixes and epilogues against the CPU oracle, 1e-4 max-abs.  usage: python tests/fuzz_gpu.py [seconds] [seed]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file lives in tests/)
 sys.path.insert(0, ROOT)
 from nnacousticmodeling_amd.engine import Engine, Model, Pipeline  # noqa: E402
 from oracle import am_oracle as orc  # noqa: E402

@@ -116,3 +116,16 @@ def test_convert_results_phone_map(golden_dir, tmp_path):
     assert lines[0] == "#!MLF!#" and lines[1] == '"lab/FDHC0_SI1559.rec"'
     assert lines[2] == "0 300000 sil" and lines[3] == "300000 900000 aa" and lines[4] == "900000 1200000 sh" and lines[5] == "."
     assert scoring.loadMlf(str(out))["lab/FDHC0_SI1559"][0] == ["sil", "aa", "sh"]
+
+
+def test_synthetic_generators_match_the_test_suites():
+    """bench.py / tools use nnacousticmodeling_amd.synthetic; the tests use the oracle's helpers: same random streams."""
+    from nnacousticmodeling_amd import synthetic as sy
+    from oracle import viterbi_oracle as vo
+    for f, args in (("make_mlp_params", (40, 16, 2, 9)), ("make_lstm_params", (40, 16, 2, 9)), ("make_gru_params", (40, 16, 2, 9)),
+                    ("make_peephole_params", (40, 16, 2, 9)), ("make_tdnn_params", (40, [8, 8], [3, 3], 9))):
+        a, b = getattr(sy, f)(np.random.default_rng(1), *args), getattr(orc, f)(np.random.default_rng(1), *args)
+        assert a.keys() == b.keys() and all(np.array_equal(a[k], b[k]) for k in a), f
+    assert np.array_equal(sy.make_offsets(np.random.default_rng(2), 20, 900), orc.make_offsets(np.random.default_rng(2), 20, 900))
+    ga, gb = sy.make_graph(np.random.default_rng(3), 6, 50), vo.make_graph(np.random.default_rng(3), 6, 50)
+    assert ga["phones"] == gb["phones"] and all(np.array_equal(ga[k], gb[k]) for k in ga if k != "phones")

@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from nnacousticmodeling_amd._lib import AM_COMBINE_LOGITS, AM_COMBINE_LOGPOST  # noqa: E402
 from nnacousticmodeling_amd.engine import Engine, Model, Pipeline  # noqa: E402
-from oracle import am_oracle as orc  # noqa: E402  (synthetic-input helpers only)
+from nnacousticmodeling_amd import synthetic as orc  # noqa: E402  (synthetic inputs; no oracle in measurement scripts)
+from nnacousticmodeling_amd.kaldi_ft import loadKaldiFeatureTransform, select_centre_frame, tile_centre_frame, tdnn_splice  # noqa: E402
 
 SEED = 20181806
 
@@ -51,8 +52,8 @@ def main():
     args = ap.parse_args()
     rng = np.random.default_rng(SEED)
     golden = os.path.join(ROOT, "tests", "golden")
-    ft = orc.load_kaldi_feature_transform(os.path.join(golden, "final.feature_transform"))
-    ftc = orc.centre_frame_transform(ft)
+    ft = loadKaldiFeatureTransform(os.path.join(golden, "final.feature_transform"))
+    ftc = select_centre_frame(loadKaldiFeatureTransform(os.path.join(golden, "final.feature_transform")))
     eng = Engine(0)
     eng.set_precision(args.precision)
     N = 57919
@@ -123,7 +124,7 @@ def main():
         for ksize in ([5, 5, 5, 5], [9, 9, 9, 9]):
             units = [1024] * 4
             params = orc.make_tdnn_params(rng, 40, units, ksize, 1909)
-            tft = orc.tdnn_frame_transform(ft, ksize)
+            tft = tile_centre_frame(loadKaldiFeatureTransform(os.path.join(golden, "final.feature_transform")), tdnn_splice(ksize))
             m = Model(eng, "tdnn", 4, params)
             p = Pipeline(eng)
             p.set_frontend(40, tft["shifts"], tft["addShift"], tft["rescale"])

@@ -22,8 +22,8 @@ from nnacousticmodeling_amd.kaldi_ft import loadKaldiFeatureTransform  # noqa: E
 from nnacousticmodeling_amd.networks import get_nn  # noqa: E402
 from nnacousticmodeling_amd.phone_recog import PhoneRecog, base_name_copy, write_mlf  # noqa: E402
 from nnacousticmodeling_amd.sharding import get_runner  # noqa: E402
-from oracle import am_oracle as orc  # noqa: E402  (synthetic-input helpers only)
-from oracle import viterbi_oracle as vo  # noqa: E402
+from nnacousticmodeling_amd import synthetic as orc  # noqa: E402  (synthetic inputs; no oracle in measurement scripts)
+from nnacousticmodeling_amd import synthetic as vo  # noqa: E402
 
 
 def main():

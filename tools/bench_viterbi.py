@@ -17,18 +17,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from nnacousticmodeling_amd.engine import Engine  # noqa: E402
 from nnacousticmodeling_amd.phone_recog import PhoneRecog  # noqa: E402
-from oracle import am_oracle as orc  # noqa: E402
-from oracle import viterbi_oracle as vo  # noqa: E402
+from nnacousticmodeling_amd import synthetic as syn  # noqa: E402  (synthetic inputs; the oracle is imported by the CPU-baseline leg only)
 
 
 def main():
     rng = np.random.default_rng(20181806)
     P, S, N, U = 48, 1909, 57919, 192
-    graph = vo.make_graph(rng, P, S)
+    graph = syn.make_graph(rng, P, S)
     T, B = len(graph["biphoneIdxIn"]), len(graph["lm"])
-    off = orc.make_offsets(rng, U, N)
+    off = syn.make_offsets(rng, U, N)
     z = (2.0 * rng.standard_normal((N, S))).astype(np.float32)
-    lp = z - orc.logsum(z, axis=1)
+    lp = (z - (np.max(z, axis=1, keepdims=True) + np.log(np.sum(np.exp(z - np.max(z, axis=1, keepdims=True)), axis=1, keepdims=True)))).astype(np.float32)
     eng = Engine(0)
     dec = PhoneRecog(eng, dict(graph, numPhones=P, numBiphones=B, numTriphones=T), -20.0, 1.0)
     dec.recognise(lp[:off[4]], off[:5])
@@ -43,6 +42,7 @@ def main():
     out = {"graph": {"phones": P, "nodes": B, "triphones": T, "states": S}, "utterances": U, "frames": N,
            "gpu_host_to_result_s": round(gpu_s, 4), "gpu_kernel_ms": round(prof["viterbi"][1], 2),
            "gpu_frames_per_s_kernel": round(N / (prof["viterbi"][1] * 1e-3)), "segments": sum(len(r) for r in res)}
+    from oracle import viterbi_oracle as vo   # CPU-baseline leg: the reference decoder built from source (oracle/_ref)
     if vo.reference_available():
         with tempfile.TemporaryDirectory() as td:
             img = os.path.join(td, "g.img")
