@@ -1631,7 +1631,7 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
     a.pp = d->pp.as<float>(); a.tt = d->tt.as<int>(); a.pout = d->pout.as<float>(); a.p = d->p.as<float>(); a.bestI = d->bestI.as<int>(); a.bestT = d->bestT.as<int>();
     a.seg_begin = d->seg_begin.as<int>(); a.seg_end = d->seg_end.as<int>(); a.seg_tri = d->seg_tri.as<int>(); a.seg_count = d->seg_count.as<int>();
     static const int64_t fs_ok = env_int("AM_VITERBI_FS", 1);
-    if (a.compact && fs_ok && n_utts > 0) {
+    if (a.compact && fs_ok && n_utts > 0 && n_utts <= 65535) {   // slots ride on gridDim.y
         // frame-synchronous: slots = utterances by length (longest first); step k advances the first n_active slots
         std::vector<int> order(n_utts);
         std::iota(order.begin(), order.end(), 0);
