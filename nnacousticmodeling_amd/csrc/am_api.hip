@@ -530,6 +530,8 @@ extern "C" int am_model_create_tdnn(am_engine* e, int n_layers, int activation, 
         Layer& Ly = m->L[l];
         const int k = ksize[l], cp = m->chan[l];
         Ly.in = cin * k; Ly.out = units[l]; Ly.in_pad = cp * k; Ly.out_pad = gemm_n_pad(units[l]);
+        Ly.out_pad_s = (int)round_up(units[l], 256);
+        for (size_t i = 0; i < (size_t)units[l] * cin * k; ++i) Ly.wmax = std::max(Ly.wmax, fabsf(W[l][i]));
         // Convolution2D weight [out, in, 1, k] (cross-correlation) -> GEMM weight over the window's taps: column j*cp + c
         std::vector<float> w((size_t)Ly.out_pad * Ly.in_pad, 0.f), bb(Ly.out_pad, 0.f);
         for (int o = 0; o < units[l]; ++o)
@@ -545,6 +547,8 @@ extern "C" int am_model_create_tdnn(am_engine* e, int n_layers, int activation, 
     if (rc == AM_OK) {
         Layer& Lo = m->L[n_layers];   // out Linear on the flattened (units, 1, 1) map
         Lo.in = cin; Lo.out = n_classes; Lo.in_pad = m->chan[n_layers]; Lo.out_pad = gemm_n_pad(n_classes);
+        Lo.out_pad_s = (int)round_up(n_classes, 256);
+        for (size_t i = 0; i < (size_t)n_classes * cin; ++i) Lo.wmax = std::max(Lo.wmax, fabsf(out_W[i]));
         std::vector<float> w((size_t)Lo.out_pad * Lo.in_pad, 0.f), bb(Lo.out_pad, 0.f);
         for (int o = 0; o < n_classes; ++o) memcpy(&w[(size_t)o * Lo.in_pad], out_W + (size_t)o * cin, sizeof(float) * cin);
         memcpy(bb.data(), out_b, sizeof(float) * n_classes);
@@ -869,6 +873,40 @@ static int tdnn_member_forward(am_pipeline* p, int mi, int64_t frames, float* ac
     return AM_OK;
 }
 
+// the same in the split-f16 precision mode: every activation plane is a hi half plane followed by a lo half plane of the
+// same (rows incl. window slack) x channels shape, i.e. the bytes of the f32 plane it replaces
+static int tdnn_member_forward_split(am_pipeline* p, int mi, int64_t frames, float* acc)
+{
+    am_engine* e = p->e;
+    am_model* m = p->members[mi];
+    int* flag = e->d_overflow.as<int>();
+    const int64_t cap = std::min<int64_t>(round_up(std::max<int64_t>(p->n, 1), GEMM_BM), tdnn_chunk_frames(m));   // frames the buffers were sized for
+    // frontend output -> halves (the f32 rows the splice kernel wrote; slack rows stay zero)
+    const size_t in_plane = tdnn_rows_needed(m, 0, cap) * (size_t)m->chan[0];
+    _Float16* Ahi = (_Float16*)p->d_in_s.p;
+    _Float16* Alo = Ahi + in_plane;
+    AM_TRY(run_kernel(e, K_SPLIT_CONVERT, [&] { return launch_split_f32(e->stream, p->d_in.as<float>(), Ahi, Alo, (size_t)frames * m->pos[0] * m->chan[0], 1.0f, flag); }));
+    for (int l = 0; l <= m->n_layers; ++l) {
+        Layer& Ly = m->L[l];
+        SplitGemmArgs g{};
+        g.Ahi = Ahi; g.Alo = Alo; g.lda = m->chan[l]; g.Whi = Ly.Whi.p; g.Wlo = Ly.Wlo.p; g.ldw = Ly.in_pad; g.bias = Ly.b_s.as<float>();
+        g.N_pad = Ly.out_pad_s; g.K_pad = Ly.in_pad; g.act = m->act; g.out_scale = 1.0f / Ly.w_scale; g.overflow = flag;
+        if (l < m->n_layers) {
+            g.M_pad = (int)round_up(frames * m->pos[l + 1], GEMM_BM);
+            g.row_p = m->pos[l + 1]; g.row_skip = m->ksize[l] - 1;
+            _Float16* Chi = (_Float16*)((l & 1) ? p->d_act1 : p->d_act0).p;
+            g.C = nullptr; g.Chi = Chi; g.Clo = Chi + tdnn_rows_needed(m, l + 1, cap) * (size_t)m->chan[l + 1]; g.ldc = Ly.out_pad_s; g.epi = EPI_ACT; g.alpha = 1.f;
+            AM_TRY(run_kernel(e, K_GEMM_SPLIT, [&] { return launch_gemm_split(e->stream, g); }));
+            Ahi = (_Float16*)g.Chi; Alo = (_Float16*)g.Clo;
+        } else {
+            g.M_pad = (int)round_up(frames, GEMM_BM);
+            g.C = acc; g.ldc = p->acc_ld; g.epi = epilogue_mode(p, mi, &g.alpha);
+            AM_TRY(run_kernel(e, K_GEMM_SPLIT, [&] { return launch_gemm_split(e->stream, g); }));
+        }
+    }
+    return AM_OK;
+}
+
 extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, int64_t n, int halo_lo, int halo_hi)
 {
     AM_TRY(check_ready(p, AM_NET_FF));
@@ -902,6 +940,8 @@ extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, i
             for (int l = 1; l <= m->n_layers; ++l) act_elems = std::max(act_elems, tdnn_rows_needed(m, l, frames) * (size_t)m->chan[l]);
         }
         AM_TRY(p->d_in.ensure(sizeof(float) * in_rows * m0->in_pad));
+        AM_TRY(p->d_in_s.ensure(sizeof(float) * in_rows * m0->in_pad));   // split-f16 mode: the same rows as hi / lo half planes
+        HIP_TRY(hipMemsetAsync(p->d_in_s.p, 0, sizeof(float) * in_rows * m0->in_pad, e->stream));
         AM_TRY(p->d_act0.ensure(sizeof(float) * act_elems));
         AM_TRY(p->d_act1.ensure(sizeof(float) * act_elems));
         HIP_TRY(hipMemsetAsync(p->d_in.p, 0, sizeof(float) * in_rows * m0->in_pad, e->stream));   // slack rows are read (x 0 weights): keep them finite
@@ -957,7 +997,6 @@ static int ff_member_forward(am_pipeline* p, int mi, int64_t rows_pad, float* ac
 static int ensure_split_weights(am_model* m)
 {
     if (m->split_state != 0) return AM_OK;
-    if (m->tdnn) { m->split_state = -1; return AM_OK; }
     am_engine* e = m->e;
     for (int l = 0; l < m->n_layers; ++l)
         if (m->L[l].out_pad % 256) { m->split_state = -1; return AM_OK; }
@@ -983,7 +1022,7 @@ static int ensure_split_weights(am_model* m)
 static bool use_split(am_pipeline* p)
 {
     if (p->e->precision != AM_PRECISION_SPLIT_F16) return false;
-    for (auto* m : p->members) if (m->split_state != 1 || m->tdnn) return false;   // TDNN layers stay on the exact path
+    for (auto* m : p->members) if (m->split_state != 1) return false;
     return true;
 }
 
@@ -1047,7 +1086,8 @@ static int ff_run_chunks(am_pipeline* p, int64_t chunk_rows, float* host_y)
         if (m0->tdnn) AM_TRY(run_kernel(e, K_SPLICE_FT, [&] { return launch_splice_tdnn(e->stream, s, m0->win, m0->in_pad, nc_pad); }));
         else AM_TRY(run_kernel(e, K_SPLICE_FT, [&] { return launch_splice_ft(e->stream, s); }));
         for (int mi = 0; mi < (int)p->members.size(); ++mi) {
-            if (m0->tdnn) AM_TRY(tdnn_member_forward(p, mi, nc_pad, p->d_acc.as<float>()));
+            if (m0->tdnn && split) AM_TRY(tdnn_member_forward_split(p, mi, nc_pad, p->d_acc.as<float>()));
+            else if (m0->tdnn) AM_TRY(tdnn_member_forward(p, mi, nc_pad, p->d_acc.as<float>()));
             else if (split) AM_TRY(ff_member_forward_split(p, mi, nc_pad, p->d_acc.as<float>()));
             else AM_TRY(ff_member_forward(p, mi, nc_pad, p->d_acc.as<float>()));
             if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(member_finish(p, mi, nc));

@@ -54,6 +54,7 @@ struct SplitGemmArgs {
     int M_pad, N_pad, K_pad;                        // multiples of GEMM_BM / 256 / 32
     int act; int epi; float alpha; float out_scale;
     int* overflow;                                  // device flag, set when an activation does not fit f16
+    int row_p = 0, row_skip = 0;                    // TDNN: windowed A rows (see GemmArgs)
 };
 hipError_t launch_gemm_split(hipStream_t s, const SplitGemmArgs& g);
 hipError_t launch_split_f32(hipStream_t s, const float* x, void* hi, void* lo, size_t n, float scale, int* overflow);

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_split_kernel(
     const _Float16* __restrict__ Ahi, const _Float16* __restrict__ Alo, int lda,
     const _Float16* __restrict__ Whi, const _Float16* __restrict__ Wlo, int ldw, const float* __restrict__ bias,
     float* __restrict__ C, _Float16* __restrict__ Chi, _Float16* __restrict__ Clo, int ldc,
-    int tiles_n, int nk, int act, int epi, float alpha, float out_scale, int* __restrict__ overflow)
+    int tiles_n, int nk, int act, int epi, float alpha, float out_scale, int* __restrict__ overflow, int row_p, int row_skip)
 {
     constexpr int BM = GEMM_BM, BN = 256, BK = 32, NW = GEMM_WM * GEMM_WN;
     constexpr int MI = 2, NI = BN / GEMM_WN / 32;
@@ -306,7 +306,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_split_kernel(
     for (int j = 0; j < A_PER_WAVE; ++j) {
         const int r = (j * NW + wave) * RPI + lane / 4;
         const int c = (lane % 4) ^ ((r >> 2) & 3);
-        aoff[j] = (size_t)(m0 + r) * lda + c * 8;
+        const int R = m0 + r;   // TDNN layers: windowed A rows, as in gemm_nt_f32_kernel
+        aoff[j] = (row_p > 0 ? (size_t)R + (size_t)(R / row_p) * row_skip : (size_t)R) * lda + c * 8;
     }
 #pragma unroll
     for (int j = 0; j < W_PER_WAVE; ++j) {
@@ -414,11 +415,11 @@ hipError_t launch_gemm_split(hipStream_t s, const SplitGemmArgs& g)
     if (g.C)
         hipLaunchKernelGGL(gemm_nt_split_kernel<true>, dim3(grid), dim3(GEMM_THREADS), GEMM_SPLIT_LDS, s, (const _Float16*)g.Ahi, (const _Float16*)g.Alo, g.lda,
                            (const _Float16*)g.Whi, (const _Float16*)g.Wlo, g.ldw, g.bias, g.C, (_Float16*)nullptr, (_Float16*)nullptr, g.ldc, tiles_n, g.K_pad / 32,
-                           g.act, g.epi, g.alpha, g.out_scale, g.overflow);
+                           g.act, g.epi, g.alpha, g.out_scale, g.overflow, g.row_p, g.row_skip);
     else
         hipLaunchKernelGGL(gemm_nt_split_kernel<false>, dim3(grid), dim3(GEMM_THREADS), GEMM_SPLIT_LDS, s, (const _Float16*)g.Ahi, (const _Float16*)g.Alo, g.lda,
                            (const _Float16*)g.Whi, (const _Float16*)g.Wlo, g.ldw, g.bias, (float*)nullptr, (_Float16*)g.Chi, (_Float16*)g.Clo, g.ldc, tiles_n, g.K_pad / 32,
-                           g.act, g.epi, g.alpha, g.out_scale, g.overflow);
+                           g.act, g.epi, g.alpha, g.out_scale, g.overflow, g.row_p, g.row_skip);
     return hipGetLastError();
 }
 

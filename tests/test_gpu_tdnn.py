@@ -69,6 +69,35 @@ def test_tdnn_evaluate_surface_a_chunks_shards_and_ensemble(engine, real_ft_path
     assert np.max(np.abs(q.forward_ff(xs) - want)) <= TOL
 
 
+def test_tdnn_split_f16_precision_mode(engine, real_ft_path):
+    """AM_PRECISION_SPLIT_F16 on the convolution GEMMs (windowed A rows of hi/lo half planes): same 1e-4 bound, no worse
+    than 2x the exact path against the float64 shadow; a width that the split kernels do not tile (300 -> 384 columns) stays
+    on the exact path by itself."""
+    rng = np.random.default_rng(12)
+    ksize = [5, 5, 5, 5]
+    ft = orc.tdnn_frame_transform(orc.load_kaldi_feature_transform(real_ft_path), ksize)
+    n = 900
+    x = rng.standard_normal((n, 40)).astype(np.float32)
+    for units in ([256, 256, 512, 256], [256, 300, 256, 256]):
+        params = orc.make_tdnn_params(rng, 40, units, ksize, 1909)
+        want = orc.predict(orc.TDNN(params, 4), x, None, False, 17, 0, ft)
+        want64 = orc.predict(orc.TDNN(params, 4, dtype=np.float64), x, None, False, 17, 0, ft)
+        p = _pipe(engine, params, 4, ft)
+        exact = p.forward_ff(x)
+        try:
+            engine.set_precision("split_f16")
+            got = p.forward_ff(x)
+            assert not p.overflowed()
+        finally:
+            engine.set_precision("f32")
+        assert np.max(np.abs(got - want)) <= TOL
+        assert np.max(np.abs(got - want64)) <= max(2.0 * np.max(np.abs(exact - want64)), 2e-5)
+        if 300 in units:
+            assert np.array_equal(got, exact)          # unsupported shape: the exact path ran
+        else:
+            assert not np.array_equal(got, exact)      # the split kernels really ran
+
+
 def test_tdnn_argument_errors(engine, real_ft_path):
     from nnacousticmodeling_amd.engine import AmError, Model, Pipeline
     rng = np.random.default_rng(1)
