@@ -171,7 +171,11 @@ def main():
     rng = np.random.default_rng(seed)
     eng = Engine(0)
     t0, it, worst, fails = time.time(), 0, (0.0, None), 0
+    last = t0
     while time.time() - t0 < budget:
+        if time.time() - last > 30:          # a progress line: long silent GPU runs are taken to be hung
+            last = time.time()
+            print("... %d iterations, %d failures, worst %.3g" % (it, fails, worst[0]), flush=True)
         err, desc = one(eng, rng, None, it)
         if not (err <= TOL):
             fails += 1
