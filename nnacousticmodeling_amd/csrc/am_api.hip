@@ -165,9 +165,10 @@ static int64_t env_int(const char* name, int64_t dflt)
     return v && *v ? atoll(v) : dflt;
 }
 static const int64_t FF_CHUNK_ROWS = std::max<int64_t>(GEMM_BM, env_int("AM_FF_CHUNK_ROWS", 1 << 18) / GEMM_BM * GEMM_BM);
-// chunk of the one-shot host-to-host call: 65,536 rows = 256 row tiles, whole rounds of 256 blocks for 4-, 5- and 8-tile
-// wide layers (one chunk-sized launch costs ~2 % more than one launch over 196,608 rows)
-static const int64_t FF_PIPE_ROWS = std::max<int64_t>(GEMM_BM, env_int("AM_FF_PIPE_ROWS", 1 << 16) / GEMM_BM * GEMM_BM);
+// chunk of the one-shot host-to-host call.  That path is bound by the download of the posteriors (7.6 KB per frame over
+// PCIe), so the chunk is sized for overlap, not for GEMM efficiency: 16,384 rows measured best (196,608 frames host to host:
+// 29.3 ms, against 30.9 at 32,768, 33.8 at 65,536 and 31.8 at 8,192 rows)
+static const int64_t FF_PIPE_ROWS = std::max<int64_t>(GEMM_BM, env_int("AM_FF_PIPE_ROWS", 1 << 14) / GEMM_BM * GEMM_BM);
 
 // ----------------------------------------------------------------------------------------------------
 // kernel launch with optional event bracketing
