@@ -441,7 +441,7 @@ extern "C" int am_model_create(am_engine* e, int kind, int n_layers, int activat
     m->e = e; ++e->children; m->kind = kind; m->n_layers = n_layers; m->act = activation;
     m->L.resize(n_layers + 1);
     m->in_dim = in_dims[0];
-    m->in_pad = (int)round_up(in_dims[0], GEMM_BK);
+    m->in_pad = (int)round_up(in_dims[0], kind == AM_NET_LSTM ? 128 : GEMM_BK);   // recurrent members of one ensemble (any cell) share the input plane
     m->C = out_dims[n_layers];
     m->C_pad = gemm_n_pad(m->C);
     int rc = AM_OK;
@@ -584,10 +584,10 @@ extern "C" int am_model_create_rnn(am_engine* e, int cell, int n_layers, int act
     m->e = e; ++e->children; m->kind = AM_NET_LSTM; m->cell = cell; m->n_layers = n_layers; m->act = activation;
     m->L.resize(n_layers + 1);
     m->in_dim = in_dim;
-    m->in_pad = (int)round_up(in_dim, 64);
+    m->in_pad = (int)round_up(in_dim, 128);   // K segments in units of the step kernels' 128-k batches
     m->C = n_classes;
     m->C_pad = gemm_n_pad(n_classes);
-    const int U = units, U_pad = (int)round_up(U, 64);
+    const int U = units, U_pad = (int)round_up(U, 128);
     int rc = AM_OK;
     for (int l = 0; l < n_layers && rc == AM_OK; ++l) {
         Layer& Ly = m->L[l];

@@ -131,10 +131,12 @@ struct RecLayerStep {
     const float* E0; const float* E1;  // element-wise inputs  [slots, U_pad] (see RecEpilogue)
     float* O0; float* O1;              // element-wise outputs [slots, U_pad]
     int n_active; int first;
+    int block0, tpb;               // set by the launcher of rec_wide_kernel
 };
 struct RecStepArgs {
     RecLayerStep L[LSTM_MAX_LAYERS];
     int n; int U_pad; int act;     // act: AM_ACT_* of the candidate state (GRU: tanh, MGRU-relu: relu)
+    int bt_groups;                 // set by the launcher of rec_wide_kernel
 };
 hipError_t launch_rec_step(hipStream_t s, int epilogue, const RecStepArgs& a);
 

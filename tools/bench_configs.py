@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--which", default="all")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--precision", default="f32", choices=["f32", "split_f16"])
+    ap.add_argument("--cell", default="", help="with --which cells: comma-separated subset of gru,mgrurelu,mgrurelur,peepholelstm")
     args = ap.parse_args()
     rng = np.random.default_rng(SEED)
     golden = os.path.join(ROOT, "tests", "golden")
@@ -141,7 +142,7 @@ def main():
             p.close()
     if args.which in ("all", "cells"):
         # the other recurrent cells of get_nn at the LSTM config's size
-        for net in ("gru", "mgrurelu", "peepholelstm"):
+        for net in (args.cell.split(",") if args.cell else ("gru", "mgrurelu", "peepholelstm")):
             if net == "peepholelstm":
                 params = orc.make_peephole_params(rng, 40, 512, 3, 1909)
                 fl = 2 * (40 * 2048 + 2 * 512 * 2048 + 3 * 512 * 2048 + 3 * 3 * 512 * 512 + 512 * 1909)
