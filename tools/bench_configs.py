@@ -108,6 +108,16 @@ def main():
             fl = 2 * (40 * 2048 + 2 * 512 * 2048 + 3 * 512 * 2048 + 512 * 1909)
             report("3x512 LSTM N=57919 192 utts Tmax=%d timedelay=%d" % (int(np.diff(offsets).max()), td), N, wall, ms, calls, fl)
             p.close()
+    if args.which in ("lstm256",):
+        params = orc.make_lstm_params(rng, 40, 256, 3, 1909)
+        m = Model(eng, "lstm", 3, params)
+        p = Pipeline(eng)
+        p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
+        p.set_members([m])
+        p.lstm_upload(x, None, offsets, 0)
+        wall, ms, calls = timed(eng, p.lstm_run, args.steps, 3)
+        report("3x256 LSTM N=57919 192 utts", N, wall, ms, calls, 2 * (40 * 1024 + 2 * 256 * 1024 + 3 * 256 * 1024 + 256 * 1909))
+        p.close()
     if args.which in ("lstm1024",):
         # the reference's own example network (scripts/examples: "lstm -l 4 -u 1024 --timedelay 5")
         params = orc.make_lstm_params(rng, 40, 1024, 4, 1909)
