@@ -1433,7 +1433,7 @@ __global__ __launch_bounds__(512) void rec_step_kernel(const RecStepArgs args)
 constexpr int REC_WIDE_ROWS = 64;
 constexpr size_t REC_WIDE_LDS = 2 * REC_WIDE_ROWS * LSTM_LDA * sizeof(float);   // 67,584 B; the exchange buffer aliases it
 
-template <int G, int EPI, int NT>
+template <int G, int EPI, int NT, bool ZW>   // ZW: the batch count is not a multiple of the 4-slot rotation (zero weights past the end)
 __device__ __forceinline__ void rec_wide_body(const RecLayerStep& Ls, int U_pad, int act, int bt, int row0, float* smem)
 {
     constexpr int NU = 16 / G, UB = 4 * NU;               // units per column tile / per block
@@ -1490,7 +1490,8 @@ __device__ __forceinline__ void rec_wide_body(const RecLayerStep& Ls, int U_pad,
 #pragma unroll
             for (int s = 0; s < LSTM_KS; ++s) {
                 const f32x4 v = *(const f32x4*)(wp + 16 * s);
-                dst[s] = real ? v : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                // without ZW the only batches past the end are the refills behind the last rotation: loaded, never multiplied
+                dst[s] = (!ZW || real) ? v : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             }
         };
         load_a(0, av[0]); load_w(0, wv[0]);
@@ -1567,12 +1568,23 @@ __global__ __launch_bounds__(512, 2) void rec_wide_kernel(const RecStepArgs args
     const int row0 = rt * Ls.tpb * 16;
     const int tiles_left = (Ls.n_active - row0 + 15) / 16;
     const int ntile = tiles_left < Ls.tpb ? tiles_left : Ls.tpb;
-    switch (ntile) {   // uniform per block
-    case 1: rec_wide_body<G, EPI, 1>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
-    case 2: rec_wide_body<G, EPI, 2>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
-    case 3: rec_wide_body<G, EPI, 3>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
-    case 4: rec_wide_body<G, EPI, 4>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
-    default: break;
+    const bool zw = (((Ls.K[0] + Ls.K[1] + Ls.K[2]) / LSTM_KB) & 3) != 0;   // uniform per block
+    if (zw) {
+        switch (ntile) {
+        case 1: rec_wide_body<G, EPI, 1, true>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
+        case 2: rec_wide_body<G, EPI, 2, true>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
+        case 3: rec_wide_body<G, EPI, 3, true>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
+        case 4: rec_wide_body<G, EPI, 4, true>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
+        default: break;
+        }
+    } else {
+        switch (ntile) {
+        case 1: rec_wide_body<G, EPI, 1, false>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
+        case 2: rec_wide_body<G, EPI, 2, false>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
+        case 3: rec_wide_body<G, EPI, 3, false>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
+        case 4: rec_wide_body<G, EPI, 4, false>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
+        default: break;
+        }
     }
 }
 
