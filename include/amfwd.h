@@ -64,11 +64,12 @@ int am_engine_device_name(am_engine* e, char* buf, int buflen);
  *   AM_PRECISION_SPLIT_F16   : every f32 operand is carried as two f16 halves (x = hi + lo) and each product is formed as
  *       lo*wh + hi*wl + hi*wh on the f16 matrix pipe with f32 accumulation -- f32-accurate (error against an f64 reference
  *       not larger than the exact path's), ~2.4x faster.  If an activation does not fit f16 the kernels raise a
- *       flag: am_forward_ff then repeats the pass on the exact path by itself; callers of am_ff_run check
- *       am_pipeline_overflowed().  The recurrent path always uses AM_PRECISION_F32. */
+ *       flag: am_forward_ff and am_ff_run then repeat the pass on the exact path by themselves (in this mode am_ff_run
+ *       synchronises to read the flag), so the resident posteriors are always valid; am_pipeline_overflowed() only
+ *       reports that this happened.  The recurrent path always uses AM_PRECISION_F32. */
 enum { AM_PRECISION_F32 = 0, AM_PRECISION_SPLIT_F16 = 1 };
 int am_engine_set_precision(am_engine* e, int precision);
-int am_pipeline_overflowed(am_pipeline* p, int* flag);   /* synchronises; flag = 1 if the last run overflowed f16 */
+int am_pipeline_overflowed(am_pipeline* p, int* flag);   /* synchronises; flag = 1 if the last run overflowed f16 (and was repeated exactly) */
 
 /* HIP events on the engine's compute stream (the stream every kernel below is launched on).
  * slot in [0, 64).  Used by bench.py for the timed region. */
@@ -209,6 +210,15 @@ int am_decoder_create(am_engine* e, int numPhones, int numBiphones, int numTriph
                       const float* tpSelfloop, const float* tpTransition, const int* outOffsets, const int* outValues,
                       const float* lm, float PIP, float LMW, am_decoder** out);
 int am_decoder_destroy(am_decoder* d);
+/* Which of the three kernel forms am_decode_* runs; all give the same segmentations.  AUTO (default) takes the
+ * frame-synchronous form when the graph fits 16-bit node / state ids and entry times, else one workgroup per utterance
+ * (main.cpp:51's parallelisation) on compact or, for larger graphs, 32-bit records.  A form that does not fit the graph
+ * or batch makes am_decode_* return AM_EINVAL (parity tests walk through all three). */
+#define AM_VITERBI_AUTO 0
+#define AM_VITERBI_FRAME_SYNC 1
+#define AM_VITERBI_PER_UTT_COMPACT 2
+#define AM_VITERBI_PER_UTT_WIDE 3
+int am_decoder_set_form(am_decoder* d, int form);
 /* lp: [offsets[n_utts], numStates] log-probabilities (what the .lab files hold), utterance u = rows
  * [offsets[u], offsets[u+1]).  Output: utterance u's segments in time order at index offsets[u] .. offsets[u] +
  * seg_count[u] - 1 of seg_begin / seg_end (frames, as written to the MLF) / seg_tri (triphone id -> phone table).

@@ -71,6 +71,7 @@ SIGNATURES = {
     "am_decoder_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p, c_float_p, c_float_p,
                                     c_int_p, c_int_p, c_float_p, C.c_float, C.c_float, c_void_pp]),
     "am_decoder_destroy": (C.c_int, [C.c_void_p]),
+    "am_decoder_set_form": (C.c_int, [C.c_void_p, C.c_int]),
     "am_decode_host": (C.c_int, [C.c_void_p, c_float_p, c_int64_p, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]),
     "am_decode_pipeline": (C.c_int, [C.c_void_p, C.c_void_p, c_int64_p, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]),
     "am_linear": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, C.c_int, c_float_p, c_float_p, C.c_int, C.c_int, c_float_p]),

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <dlfcn.h>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -132,12 +133,14 @@ struct am_pipeline {
     int normalise = 1;
     // resident state
     int mode = 0;  // 0 nothing uploaded, 1 ff, 2 lstm
+    bool results_valid = false;  // d_out holds the posteriors of the current upload (set by the run calls, cleared by upload / set_*)
     int64_t n = 0;
     int halo_lo = 0, halo_hi = 0;
     bool has_ivec = false;
     DevBuf d_x, d_ivec, d_in, d_in_s, d_act0, d_act1, d_acc, d_acc2, d_out;
     int acc_ld = 0;        // leading dimension of d_acc / d_acc2 in the current run (C_pad, or C padded to 256 in split mode)
     bool ran_split = false;
+    bool fell_back = false;  // the last split-f16 run overflowed f16 and was repeated on the exact path
     std::vector<hipEvent_t> chunk_done;  // one-shot path: chunk c's posteriors are final (compute stream -> copy stream)
     // lstm
     DevBuf d_src, d_dst, d_G, d_H, d_c;   // d_H / d_c: one packed H plane and one cell-state array per layer
@@ -155,6 +158,7 @@ struct am_pipeline {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (graph) (void)hipGraphDestroy(graph);
         graph_exec = nullptr; graph = nullptr; lstm_runs = 0;
+        results_valid = false;   // every caller is an upload or a configuration change
     }
 };
 
@@ -169,6 +173,27 @@ static const int64_t FF_CHUNK_ROWS = std::max<int64_t>(GEMM_BM, env_int("AM_FF_C
 // PCIe), so the chunk is sized for overlap, not for GEMM efficiency: 16,384 rows measured best (196,608 frames host to host:
 // 29.3 ms, against 30.9 at 32,768, 33.8 at 65,536 and 31.8 at 8,192 rows)
 static const int64_t FF_PIPE_ROWS = std::max<int64_t>(GEMM_BM, env_int("AM_FF_PIPE_ROWS", 1 << 14) / GEMM_BM * GEMM_BM);
+
+// Whether am_lstm_run replays the recurrent launch sequence from a hipGraph (AM_LSTM_GRAPH=1 / 0 forces it on / off).
+// Default: on, except when a queue-intercepting tool (rocprofv3 / rocprof / an HSA tools library) is loaded in the
+// process.  ROCm 7.2's intercept path reads past the end of the 16,384-packet AQL ring when a graph's pre-built packet
+// batch straddles the ring's wrap point: SIGSEGV inside hipGraphLaunch at a 2^20-aligned address, reproduced to the
+// exact pass by tools/repro_graph_wrap.py.  Eager launches write one packet at a time and are
+// not affected; a tracing profiler costs tens of microseconds per kernel anyway, so nothing is lost.
+static bool lstm_use_graph()
+{
+    static const int mode = [] {
+        const int64_t forced = env_int("AM_LSTM_GRAPH", -1);
+        if (forced >= 0) return forced != 0 ? 1 : 0;
+        for (const char* v : {"ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_LIBRARY"}) {
+            const char* s = getenv(v);
+            if (s && *s) return 0;
+        }
+        if (dlsym(RTLD_DEFAULT, "rocprofiler_configure")) return 0;   // a rocprofiler-sdk tool was preloaded
+        return 1;
+    }();
+    return mode != 0;
+}
 
 // ----------------------------------------------------------------------------------------------------
 // kernel launch with optional event bracketing
@@ -343,13 +368,15 @@ extern "C" int am_engine_set_precision(am_engine* e, int precision)
 extern "C" int am_pipeline_overflowed(am_pipeline* p, int* flag)
 {
     if (!p || !flag) return fail(AM_EINVAL, "am_pipeline_overflowed: bad argument");
-    *flag = 0;
+    *flag = p->fell_back ? 1 : 0;
     if (!p->ran_split) return AM_OK;
     am_engine* e = p->e;
     HIP_TRY(hipSetDevice(e->device));
     AM_TRY(join_streams(e));
-    HIP_TRY(hipMemcpyAsync(flag, e->d_overflow.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    int raised = 0;
+    HIP_TRY(hipMemcpyAsync(&raised, e->d_overflow.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    if (raised) *flag = 1;
     return AM_OK;
 }
 
@@ -962,7 +989,7 @@ extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, i
     AM_TRY(p->d_out.ensure(std::max<size_t>(sizeof(float) * n * m0->C, 16)));
     AM_TRY(sync_all(e));
     p->n = n; p->halo_lo = halo_lo; p->halo_hi = halo_hi; p->has_ivec = ivec != nullptr;
-    p->mode = 1;
+    p->mode = 1; p->results_valid = false;
     return AM_OK;
 }
 
@@ -1120,12 +1147,28 @@ extern "C" int am_ff_run(am_pipeline* p)
 {
     if (!p || p->mode != 1) return fail(AM_EINVAL, "am_ff_run: nothing uploaded (am_ff_upload)");
     HIP_TRY(hipSetDevice(p->e->device));
-    return ff_run_chunks(p, FF_CHUNK_ROWS, nullptr);
+    p->fell_back = false;
+    AM_TRY(ff_run_chunks(p, FF_CHUNK_ROWS, nullptr));
+    p->results_valid = true;
+    if (p->ran_split) {   // split-f16 mode: an activation that does not fit f16 sends the whole pass to the exact f32 path
+        int over = 0;     // (this read synchronises; the exact path stays asynchronous)
+        AM_TRY(am_pipeline_overflowed(p, &over));
+        if (over) {
+            const int keep = p->e->precision;
+            p->e->precision = AM_PRECISION_F32;
+            const int rc = ff_run_chunks(p, FF_CHUNK_ROWS, nullptr);
+            p->e->precision = keep;
+            AM_TRY(rc);
+            p->fell_back = true;
+        }
+    }
+    return AM_OK;
 }
 
 extern "C" int am_ff_download(am_pipeline* p, float* y)
 {
     if (!p || p->mode != 1 || !y) return fail(AM_EINVAL, "am_ff_download: nothing to download");
+    if (!p->results_valid) return fail(AM_EINVAL, "am_ff_download: the pipeline has not been run since its last upload / configuration change");
     am_engine* e = p->e;
     HIP_TRY(hipSetDevice(e->device));
     AM_TRY(join_streams(e));
@@ -1138,7 +1181,9 @@ extern "C" int am_forward_ff(am_pipeline* p, const float* x, const float* ivec, 
 {
     AM_TRY(am_ff_upload(p, x, ivec, n, halo_lo, halo_hi));
     if (!y) return fail(AM_EINVAL, "am_forward_ff: y is NULL");
+    p->fell_back = false;
     AM_TRY(ff_run_chunks(p, FF_PIPE_ROWS, y));   // download of chunk c overlaps the compute of chunk c+1
+    p->results_valid = true;
     AM_TRY(sync_all(p->e));
     int over = 0;
     AM_TRY(am_pipeline_overflowed(p, &over));
@@ -1148,6 +1193,7 @@ extern "C" int am_forward_ff(am_pipeline* p, const float* x, const float* ivec, 
         const int rc = ff_run_chunks(p, FF_PIPE_ROWS, y);
         p->e->precision = keep;
         AM_TRY(rc);
+        p->fell_back = true;
         AM_TRY(sync_all(p->e));
     }
     return AM_OK;
@@ -1243,17 +1289,19 @@ extern "C" int am_lstm_run(am_pipeline* p)
     if (!p || p->mode != 2) return fail(AM_EINVAL, "am_lstm_run: nothing uploaded (am_lstm_upload)");
     am_engine* e = p->e;
     HIP_TRY(hipSetDevice(e->device));
+    p->results_valid = true;   // (cleared again below if the enqueue fails)
     if (p->n_packed == 0) return AM_OK;
-    if (e->profile) return lstm_enqueue(p);           // per-kernel events need eager launches
+    auto eager = [&] { const int rc = lstm_enqueue(p); if (rc != AM_OK) p->results_valid = false; return rc; };
+    if (e->profile || !lstm_use_graph()) return eager();   // per-kernel events need eager launches
     if (p->graph_exec) { HIP_TRY(hipGraphLaunch(p->graph_exec, e->stream)); return AM_OK; }
-    if (p->lstm_runs++ == 0) return lstm_enqueue(p);  // one-shot use: eager (no capture / instantiate cost)
+    if (p->lstm_runs++ == 0) return eager();          // one-shot use: eager (no capture / instantiate cost)
     // second run on the same upload: capture the launch sequence once, then replay it
     HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
     const int rc = lstm_enqueue(p);
     hipGraph_t g = nullptr;
     hipError_t ce = hipStreamEndCapture(e->stream, &g);
-    if (rc != AM_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
-    if (ce != hipSuccess) return fail(AM_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+    if (rc != AM_OK) { if (g) (void)hipGraphDestroy(g); p->results_valid = false; return rc; }
+    if (ce != hipSuccess) { p->results_valid = false; return fail(AM_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce)); }
     p->graph = g;
     HIP_TRY(hipGraphInstantiate(&p->graph_exec, p->graph, nullptr, nullptr, 0));
     HIP_TRY(hipGraphLaunch(p->graph_exec, e->stream));
@@ -1410,6 +1458,7 @@ static int lstm_enqueue(am_pipeline* p)
 extern "C" int am_lstm_download(am_pipeline* p, float* y)
 {
     if (!p || p->mode != 2 || !y) return fail(AM_EINVAL, "am_lstm_download: nothing to download");
+    if (!p->results_valid) return fail(AM_EINVAL, "am_lstm_download: the pipeline has not been run since its last upload / configuration change");
     am_engine* e = p->e;
     HIP_TRY(hipSetDevice(e->device));
     AM_TRY(join_streams(e));
@@ -1526,6 +1575,7 @@ struct am_decoder {
     DevBuf d_slot;       // frame-synchronous form: slot -> utterance
     DevBuf cmp0, cmp1;   // compact 32-B graph records (nodes and posterior columns < 65536), see viterbi_compact_kernel
     bool has_compact = false;
+    int form = AM_VITERBI_AUTO;   // am_decoder_set_form
     int perm = 0, inv0 = 0;   // compact records stored in arrival-list order (see ViterbiArgs::perm)
     DevBuf d_lp, d_off, pp, tt, pout, p, bestI, bestT, seg_begin, seg_end, seg_tri, seg_count;
 };
@@ -1621,6 +1671,13 @@ extern "C" int am_decoder_create(am_engine* e, int numPhones, int numBiphones, i
     return AM_OK;
 }
 
+extern "C" int am_decoder_set_form(am_decoder* d, int form)
+{
+    if (!d || form < AM_VITERBI_AUTO || form > AM_VITERBI_PER_UTT_WIDE) return fail(AM_EINVAL, "am_decoder_set_form: bad argument");
+    d->form = form;
+    return AM_OK;
+}
+
 extern "C" int am_decoder_destroy(am_decoder* d)
 {
     if (!d) return AM_OK;
@@ -1661,8 +1718,13 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
     a.tri_idx = (decltype(a.tri_idx))d->tri_idx.p; a.tri_self = (decltype(a.tri_self))d->tri_self.p; a.tri_trans = (decltype(a.tri_trans))d->tri_trans.p;
     int64_t longest = 0;
     for (int u = 0; u < n_utts; ++u) longest = std::max(longest, offsets[u + 1] - offsets[u]);
-    static const int64_t compact_ok = env_int("AM_VITERBI_COMPACT", 1);
-    if (d->has_compact && longest < 65535 && compact_ok) {   // entry times travel as 16-bit (t + 1)
+    static const int64_t compact_env = env_int("AM_VITERBI_COMPACT", 1);
+    const bool compact_fits = d->has_compact && longest < 65535;   // entry times travel as 16-bit (t + 1)
+    const bool fs_fits = compact_fits && n_utts > 0 && n_utts <= 65535;   // slots ride on gridDim.y
+    if (d->form == AM_VITERBI_FRAME_SYNC && !fs_fits && n_utts > 0) return fail(AM_EINVAL, "am_decode: the frame-synchronous form does not fit this graph / batch");
+    if (d->form == AM_VITERBI_PER_UTT_COMPACT && !compact_fits) return fail(AM_EINVAL, "am_decode: the compact form does not fit this graph / batch");
+    const bool compact_ok = d->form == AM_VITERBI_AUTO ? compact_env != 0 : d->form != AM_VITERBI_PER_UTT_WIDE;
+    if (compact_fits && compact_ok) {
         a.compact = 1; a.perm = d->perm; a.inv0 = d->inv0;
         a.tri_idx = (decltype(a.tri_idx))d->cmp0.p; a.tri_self = (decltype(a.tri_self))d->cmp1.p;
     }
@@ -1671,8 +1733,9 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
     a.lp = lp_dev; a.ldl = ld; a.offsets = d->d_off.as<long long>();
     a.pp = d->pp.as<float>(); a.tt = d->tt.as<int>(); a.pout = d->pout.as<float>(); a.p = d->p.as<float>(); a.bestI = d->bestI.as<int>(); a.bestT = d->bestT.as<int>();
     a.seg_begin = d->seg_begin.as<int>(); a.seg_end = d->seg_end.as<int>(); a.seg_tri = d->seg_tri.as<int>(); a.seg_count = d->seg_count.as<int>();
-    static const int64_t fs_ok = env_int("AM_VITERBI_FS", 1);
-    if (a.compact && fs_ok && n_utts > 0 && n_utts <= 65535) {   // slots ride on gridDim.y
+    static const int64_t fs_env = env_int("AM_VITERBI_FS", 1);
+    const bool fs_ok = d->form == AM_VITERBI_AUTO ? fs_env != 0 : d->form == AM_VITERBI_FRAME_SYNC;
+    if (a.compact && fs_ok && fs_fits) {
         // frame-synchronous: slots = utterances by length (longest first); step k advances the first n_active slots
         std::vector<int> order(n_utts);
         std::iota(order.begin(), order.end(), 0);
@@ -1727,7 +1790,7 @@ extern "C" int am_decode_pipeline(am_decoder* d, am_pipeline* p, const int64_t* 
 {
     if (!d || !p || !offsets || n_utts < 0 || !seg_begin || !seg_end || !seg_tri || !seg_count || offsets[0] != 0) return fail(AM_EINVAL, "am_decode_pipeline: bad argument");
     if (p->e != d->e) return fail(AM_EINVAL, "am_decode_pipeline: decoder and pipeline live on different engines");
-    if (p->mode == 0) return fail(AM_EINVAL, "am_decode_pipeline: the pipeline holds no posteriors (run it first)");
+    if (p->mode == 0 || !p->results_valid) return fail(AM_EINVAL, "am_decode_pipeline: the pipeline holds no posteriors (run it first)");
     if (p->members[0]->C != d->S) return fail(AM_EINVAL, "Num states in log-probs file and model image differ!");
     if (offsets[n_utts] != p->n) return fail(AM_EINVAL, "am_decode_pipeline: offsets cover %lld frames, the pipeline holds %lld", (long long)offsets[n_utts], (long long)p->n);
     HIP_TRY(hipSetDevice(d->e->device));

@@ -93,6 +93,12 @@ class PhoneRecog:
         check(self._lib.am_decoder_create(engine._h, P, B, T, S, *[ptr(a) for a in arrs], float(PIP), float(LMW), C.byref(h)))
         self._h = h
 
+    FORMS = {"auto": 0, "frame_sync": 1, "per_utt_compact": 2, "per_utt_wide": 3}
+
+    def set_form(self, form):
+        """Kernel form (include/amfwd.h AM_VITERBI_*): "auto", "frame_sync", "per_utt_compact", "per_utt_wide"."""
+        check(self._lib.am_decoder_set_form(self._h, self.FORMS[form]))
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.am_decoder_destroy(self._h)

@@ -61,56 +61,103 @@ def gather_utterances(x, offsets, utts):
 # ---------------------------------------------------------------------------------------------------
 # runner
 # ---------------------------------------------------------------------------------------------------
-class _DeviceState:
+class _ShardState:
+    """One logical shard: its own engine (streams, workspace), pipeline and resident models on one GPU."""
+
     def __init__(self, backend, device):
         self.engine = backend.Engine(device)
-        self.models = {}
+        self.models = []          # [(spec, Model)]: holds the spec itself, never a bare id() (ids are reused after GC)
         self.pipeline = backend.Pipeline(self.engine)
+
+    def model_for(self, backend, spec):
+        for sp, m in self.models:
+            if sp is spec:
+                return m
+        if spec.params is None:
+            raise ValueError("network has no parameters loaded (chainer_npz.load_npz)")
+        m = backend.Model(self.engine, spec.network, spec.layers, spec.params, spec.activation)
+        self.models.append((spec, m))
+        return m
+
+    def evict_except(self, keep):
+        """Close the device copies of every model that is not part of the ensemble being configured (per-fold mode
+        walks through the folds one at a time: the previous fold's weights leave HBM here)."""
+        kept = []
+        for sp, m in self.models:
+            if any(sp is k for k in keep):
+                kept.append((sp, m))
+            else:
+                m.close()
+        self.models = kept
+
+
+def _normalise_shards(devices):
+    """``devices``: GPU ids, or (gpu, replica) pairs.  Several logical shards may share one GPU (each gets its own engine:
+    two shards of one card overlap one's transfers with the other's compute, and the threaded shard / gather code runs on a
+    single-GPU box exactly as it does on eight).  -> [(gpu, replica)] with replicas numbered per GPU."""
+    out, seen = [], {}
+    for d in devices:
+        if isinstance(d, (tuple, list)):
+            gpu, rep = int(d[0]), int(d[1])
+        else:
+            gpu = int(d)
+            rep = seen.get(gpu, 0)
+        if gpu < 0:
+            raise ValueError("negative GPU id (CPU execution) is not supported: this path has no CPU fallback")
+        seen[gpu] = max(seen.get(gpu, 0), rep + 1)
+        if (gpu, rep) in out:
+            raise ValueError("shard (%d, %d) listed twice" % (gpu, rep))
+        out.append((gpu, rep))
+    if not out:
+        raise ValueError("no device given")
+    return out
 
 
 class PosteriorRunner:
     """Runs an ensemble (``NetworkSpec`` or ``NNWithRPL``) on one or more GPUs.
 
-    ``devices``: list of device ids.  ``backend``: module providing Engine/Model/Pipeline (default: the HIP engine;
-    the CPU-only test-suite injects a stand-in to exercise this host logic without a GPU)."""
+    ``devices``: list of device ids, or of ``(device, replica)`` pairs for several logical shards per GPU.
+    ``backend``: module providing Engine/Model/Pipeline (default: the HIP engine; the CPU-only test-suite injects a
+    stand-in to exercise this host logic without a GPU)."""
 
     def __init__(self, devices=(0,), backend=None, precision="f32"):
         if backend is None:
             from . import engine as backend
         self.backend = backend
         self.precision = precision   # "f32" (exact f32 MFMA) or "split_f16" (f32-accurate on the f16 pipe, feed-forward only)
-        self.devices = [int(d) for d in devices]
-        if not self.devices:
-            raise ValueError("no device given")
-        for d in self.devices:
-            if d < 0:
-                raise ValueError("negative GPU id (CPU execution) is not supported: this path has no CPU fallback")
+        self.shards = _normalise_shards(devices)
+        self.devices = [g for g, _ in self.shards]
         self._state = {}
         self._lock = threading.Lock()
 
-    def _dev(self, device):
+    def _dev(self, shard):
+        if not isinstance(shard, tuple):
+            shard = (int(shard), 0)
         with self._lock:
-            st = self._state.get(device)
+            st = self._state.get(shard)
             if st is None:
-                st = self._state[device] = _DeviceState(self.backend, device)
+                st = self._state[shard] = _ShardState(self.backend, shard[0])
                 if self.precision != "f32":
                     st.engine.set_precision(self.precision)
             return st
 
+    def _out(self, n, c, zero=False):
+        """The gathered [N, C] array.  Page-locked when the backend offers it (am_host_alloc): every shard's download then
+        runs at PCIe rate straight into its slice, instead of being staged through the driver's bounce buffers."""
+        alloc = getattr(self.backend, "pinned_empty", None)
+        y = alloc((n, c), np.float32) if (alloc is not None and n * c > 0) else np.empty((n, c), dtype=np.float32)
+        if zero:
+            y[...] = 0.0
+        return y
+
     def _configure(self, st, ensemble, D, shifts, ft, d_iv, prior, combine, normalise):
-        members = []
-        for spec in ensemble.members():
-            key = id(spec)
-            m = st.models.get(key)
-            if m is None:
-                if spec.params is None:
-                    raise ValueError("network has no parameters loaded (chainer_npz.load_npz)")
-                m = st.models[key] = self.backend.Model(st.engine, spec.network, spec.layers, spec.params, spec.activation)
-            members.append(m)
+        specs = list(ensemble.members())
+        members = [st.model_for(self.backend, spec) for spec in specs]
         p = st.pipeline
         add, scale = (None, None) if ft is None else (ft["addShift"], ft["rescale"])
         p.set_frontend(D, shifts, add, scale, d_iv)
         p.set_members(members, has_master=ensemble.has_master and combine == AM_COMBINE_LOGITS, combine=combine)
+        st.evict_except(specs)   # after set_members: the pipeline no longer refers to the models closed here
         rpl = ensemble.rpl
         if rpl is not None:
             p.set_rpl4(rpl.W, rpl.b, rpl.lb)
@@ -121,7 +168,7 @@ class PosteriorRunner:
         return p
 
     def _run_parallel(self, jobs):
-        """jobs: list of (device, callable).  One thread per job; first exception is re-raised."""
+        """jobs: list of (shard, callable).  One thread per job; first exception is re-raised."""
         if len(jobs) == 1:
             jobs[0][1]()
             return
@@ -151,15 +198,15 @@ class PosteriorRunner:
         d_iv = 0 if iv is None else iv.shape[1]
         shifts = [int(s) for s in shifts]
         ctx = max(abs(s) for s in shifts)
-        y = np.empty((n, ens.num_classes), dtype=np.float32)
-        shards = ff_shards(n, len(self.devices), ctx)
+        y = self._out(n, ens.num_classes)
+        shards = ff_shards(n, len(self.shards), ctx)
         jobs = []
-        for (lo, hi, h_lo, h_hi), dev in zip(shards, self.devices):
-            def job(lo=lo, hi=hi, h_lo=h_lo, h_hi=h_hi, dev=dev):
-                st = self._dev(dev)
+        for (lo, hi, h_lo, h_hi), shard in zip(shards, self.shards):
+            def job(lo=lo, hi=hi, h_lo=h_lo, h_hi=h_hi, shard=shard):
+                st = self._dev(shard)
                 p = self._configure(st, ens, D, shifts, ft, d_iv, prior, combine, normalise)
                 p.forward_ff(x[lo - h_lo:hi + h_hi], None if iv is None else iv[lo:hi], hi - lo, h_lo, h_hi, out=y[lo:hi])
-            jobs.append((dev, job))
+            jobs.append((shard, job))
         if jobs:
             self._run_parallel(jobs)
         return y
@@ -173,22 +220,22 @@ class PosteriorRunner:
         n, D = x.shape
         iv = None if ivectors is None else np.ascontiguousarray(ivectors, dtype=np.float32)
         d_iv = 0 if iv is None else iv.shape[1]
-        y = np.zeros((n, ens.num_classes), dtype=np.float32)
-        bins = lstm_bins(offsets, len(self.devices))
+        y = self._out(n, ens.num_classes, zero=True)
+        bins = lstm_bins(offsets, len(self.shards))
         jobs = []
-        for utts, dev in zip(bins, self.devices):
-            def job(utts=utts, dev=dev):
-                st = self._dev(dev)
+        for utts, shard in zip(bins, self.shards):
+            def job(utts=utts, shard=shard):
+                st = self._dev(shard)
                 p = self._configure(st, ens, D, [0], ft, d_iv, prior, combine, normalise)
                 if len(bins) == 1:
                     p.forward_lstm(x, offsets, iv, timedelay, out=y)
                     return
                 xs, local = gather_utterances(x, offsets, utts)
                 ivs = None if iv is None else gather_utterances(iv, offsets, utts)[0]
-                ys = p.forward_lstm(xs, local, ivs, timedelay)
+                ys = p.forward_lstm(xs, local, ivs, timedelay, out=self._out(xs.shape[0], ens.num_classes))
                 for j, u in enumerate(utts):
                     y[offsets[u]:offsets[u + 1]] = ys[local[j]:local[j + 1]]
-            jobs.append((dev, job))
+            jobs.append((shard, job))
         if jobs:
             self._run_parallel(jobs)
         return y
@@ -196,14 +243,15 @@ class PosteriorRunner:
     # device-resident variants (single GPU): the posteriors stay in the pipeline's device memory -------------------
     def resident(self, model, x, offsets=None, shifts=(0,), ft=None, ivectors=None, prior=None, recurrent=False, normalise=True):
         """Upload + run without the download: returns the pipeline that now holds the [N, C] posteriors on the GPU
-        (``PhoneRecog.recognise_pipeline`` decodes them in place).  One device only."""
-        if len(self.devices) != 1:
+        (``PhoneRecog.recognise_pipeline`` decodes them in place).  One shard only.  In split-f16 mode ``ff_run`` itself
+        repeats the pass on the exact f32 path when an activation does not fit f16 (am_ff_run)."""
+        if len(self.shards) != 1:
             raise ValueError("device-resident posteriors need a single-GPU runner")
         ens = as_ensemble(model)
         x = np.ascontiguousarray(x, dtype=np.float32)
         iv = None if ivectors is None else np.ascontiguousarray(ivectors, dtype=np.float32)
         d_iv = 0 if iv is None else iv.shape[1]
-        st = self._dev(self.devices[0])
+        st = self._dev(self.shards[0])
         shifts = [0] if recurrent else [int(s) for s in shifts]
         p = self._configure(st, ens, x.shape[1], shifts, ft, d_iv, prior, AM_COMBINE_LOGITS, normalise)
         if recurrent:
@@ -217,7 +265,7 @@ class PosteriorRunner:
     def close(self):
         for st in self._state.values():
             st.pipeline.close()
-            for m in st.models.values():
+            for _, m in st.models:
                 m.close()
             st.engine.close()
         self._state = {}
@@ -238,8 +286,8 @@ def set_default_precision(mode):
 
 
 def get_runner(devices):
-    """Process-wide cache of runners keyed by the device tuple and precision (models stay resident across calls)."""
-    key = tuple(int(d) for d in devices) + (_default_precision,)
+    """Process-wide cache of runners keyed by the shard tuple and precision (models stay resident across calls)."""
+    key = tuple(tuple(d) if isinstance(d, (tuple, list)) else int(d) for d in devices) + (_default_precision,)
     r = _default_runners.get(key)
     if r is None:
         r = _default_runners[key] = PosteriorRunner(key[:-1], precision=_default_precision)

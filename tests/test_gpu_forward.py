@@ -334,14 +334,38 @@ def test_split_f16_precision_mode(engine, real_ft_path, real_priors):
         pb = _pipe(engine)
         pb.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
         pb.set_members([_mk(engine, "ff", 4, big)])
-        pb.ff_upload(x, None, n, 0, 0)
-        pb.ff_run()
-        assert pb.overflowed()
         want_b = orc.predict(orc.MLP(big, 4), x, None, False, 11, 0, ft)
-        got_b = pb.forward_ff(x)   # automatic exact re-run
-        assert np.all(np.isfinite(got_b)) and np.max(np.abs(got_b - want_b)) <= TOL
+        pb.ff_upload(x, None, n, 0, 0)
+        pb.ff_run()                # resident path: the run itself repeats the pass on the exact path
+        assert pb.overflowed()     # ... and reports that it did
+        res_b = pb.ff_download()
+        assert np.all(np.isfinite(res_b)) and np.max(np.abs(res_b - want_b)) <= TOL
+        got_b = pb.forward_ff(x)   # one-shot call: automatic exact re-run too
+        assert pb.overflowed() and np.array_equal(got_b, res_b)
+        # evaluate --no-lab: PosteriorRunner.resident() hands the pipeline to the in-place decoder without a download;
+        # with overflowing activations the decoded posteriors must be the exact path's
+        from nnacousticmodeling_amd import networks, sharding
+        from nnacousticmodeling_amd.phone_recog import PhoneRecog
+        from oracle import viterbi_oracle as vo
+        graph = vo.make_graph(np.random.default_rng(3), 5, 1909)
+        gdict = dict(graph, numPhones=5, numBiphones=len(graph["lm"]), numTriphones=len(graph["biphoneIdxIn"]))
+        offs = np.array([0, 300, 700, n], dtype=np.int64)
+        runner = sharding.PosteriorRunner([0], precision="split_f16")
+        try:
+            spec_b = networks.get_nn("ff", 4, [1024], 1909).set_params(big)
+            pr = runner.resident(spec_b, x, offs, shifts=ft["shifts"], ft=ft)
+            assert pr.overflowed()
+            dec = PhoneRecog(pr.engine, gdict, -4.0, 1.0)
+            segs = dec.recognise_pipeline(pr, offs)
+            assert np.array_equal(pr.ff_download(), res_b)
+            dec.close()
+        finally:
+            runner.close()
+        dec2 = PhoneRecog(engine, gdict, -4.0, 1.0)
+        assert dec2.recognise(res_b, offs) == segs
+        dec2.close()
         engine.set_precision("f32")
-        assert np.array_equal(pb.forward_ff(x), got_b)
+        assert np.array_equal(pb.forward_ff(x), got_b) and not pb.overflowed()
         # a hidden width that the exact path pads to 384 is not eligible: the mode silently stays exact
         p384 = orc.make_mlp_params(rng, 440, 384, 1, 1909)
         engine.set_precision("split_f16")

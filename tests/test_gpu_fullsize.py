@@ -113,14 +113,142 @@ def test_edge_cases(engine, real_ft_path):
     assert np.max(np.abs(got - want)) <= TOL and np.all(got[0:2] == 0) and np.all(got[3:6] == 0)
 
 
-def test_multi_device_runner_on_one_gpu(engine, real_ft_path):
-    """The sharded host path (threads + host gather) with two logical shards mapped onto device 0."""
+def _rpl(rng, c=1909):
+    return {"W": (0.05 * rng.standard_normal((1, c))).astype(np.float32), "b": (0.1 * rng.standard_normal((1, c))).astype(np.float32),
+            "lb": np.full((1, c), -20.0, dtype=np.float32) + rng.standard_normal((1, c)).astype(np.float32)}
+
+
+def test_threaded_multi_shard_runner_on_one_gpu(real_ft_path, real_priors):
+    """The product's multi-GPU path (sharding.PosteriorRunner: one host thread + one engine per logical shard, frame ranges
+    with halo / longest-first utterance bins, gather into one page-locked array) run for real with 4 feed-forward shards
+    and 3 recurrent bins -- all mapped onto device 0, the hardware this box has.  Feed-forward rows are independent, so the
+    sharded result must equal the single-shard one BIT FOR BIT (single net and NNWithRPL with master + RPL4 + priors +
+    i-vectors); the recurrent kernels' summation order is a property of the K index alone, so the binned result must be
+    bit-identical too, and within 1e-4 of the oracle."""
     from nnacousticmodeling_amd import networks, sharding
+    from nnacousticmodeling_amd._lib import AM_COMBINE_LOGPOST
     rng = np.random.default_rng(8)
     ft = orc.load_kaldi_feature_transform(real_ft_path)
-    params = orc.make_mlp_params(rng, 440, 128, 2, 1909)
-    spec = networks.get_nn("ff", 2, [128], 1909).set_params(params)
-    x = rng.standard_normal((2000, 40)).astype(np.float32)
-    one = sharding.PosteriorRunner([0]).forward_ff(spec, x, shifts=range(-5, 6), ft=ft)
-    want = orc.predict(orc.MLP(params, 2), x, None, False, 11, 0, ft)
-    assert np.max(np.abs(one - want)) <= TOL
+    n = 20011
+    x = rng.standard_normal((n, 40)).astype(np.float32)
+    iv = rng.standard_normal((n, 20)).astype(np.float32)
+    one = sharding.PosteriorRunner([0])
+    many = sharding.PosteriorRunner([(0, 0), (0, 1), (0, 2), (0, 3)])
+    assert len(many.shards) == 4
+    try:
+        # single network, spliced + i-vectors, priors
+        params = orc.make_mlp_params(rng, 460, 256, 3, 1909)
+        spec = networks.get_nn("ff", 3, [256], 1909).set_params(params)
+        a = one.forward_ff(spec, x, shifts=range(-5, 6), ft=ft, ivectors=iv, prior=real_priors)
+        b = many.forward_ff(spec, x, shifts=range(-5, 6), ft=ft, ivectors=iv, prior=real_priors)
+        assert len(many._state) == 4 and np.array_equal(a, b)
+        rows = _sample_rows(n, rng, 48)
+        feats = np.concatenate((orc.apply_feature_transform(orc.prepare_batch(x, rows, 11), ft), iv[rows]), axis=1)
+        want = orc.MLP(params, 3)(feats) - real_priors
+        assert np.max(np.abs(b[rows] - (want - orc.logsum(want, axis=1)))) <= TOL
+        # NNWithRPL: master + 3 folds + RPL4, and the dev-mode log-posterior mean
+        plist = [orc.make_mlp_params(rng, 440, 128, 2, 1909) for _ in range(4)]
+        specs = [networks.get_nn("ff", 2, [128], 1909).set_params(q) for q in plist]
+        rp = _rpl(rng)
+        ens = networks.NNWithRPL(specs[0], specs[1:], networks.RPL4Spec(1909).set_params(rp))
+        a = one.forward_ff(ens, x, shifts=range(-5, 6), ft=ft, prior=real_priors)
+        b = many.forward_ff(ens, x, shifts=range(-5, 6), ft=ft, prior=real_priors)
+        assert np.array_equal(a, b)
+        data = orc.evaluate_frontend(x[:600], 5, ft)
+        om = orc.NNWithRPL(orc.MLP(plist[0], 2), [orc.MLP(q, 2) for q in plist[1:]], orc.RPL4(rp))
+        want = np.concatenate(orc.evaluate_posteriors(om, data, np.array([0, 600]), ap=real_priors))
+        assert np.max(np.abs(b[:590] - want[:590])) <= TOL   # the last rows of the 600-row excerpt clamp differently
+        folds = networks.NNWithRPL(None, specs[1:], None)
+        a = one.forward_ff(folds, x, shifts=range(-5, 6), ft=ft, combine=AM_COMBINE_LOGPOST)
+        b = many.forward_ff(folds, x, shifts=range(-5, 6), ft=ft, combine=AM_COMBINE_LOGPOST)
+        assert np.array_equal(a, b)
+        # recurrent: 3 bins of whole utterances; single net (predict: timedelay) and NNWithRPL (evaluate: priors)
+        three = sharding.PosteriorRunner([(0, 0), (0, 1), (0, 2)])
+        try:
+            ftc = orc.centre_frame_transform(ft)
+            off = orc.make_offsets(rng, 40, 6000, lo=40, hi=400)
+            xr = rng.standard_normal((6000, 40)).astype(np.float32)
+            lp = [orc.make_lstm_params(rng, 40, 128, 2, 1909) for _ in range(3)]
+            ls = [networks.get_nn("lstm", 2, [128], 1909).set_params(q) for q in lp]
+            a = one.forward_lstm(ls[0], xr, off, ft=ftc, timedelay=3)
+            b = three.forward_lstm(ls[0], xr, off, ft=ftc, timedelay=3)
+            assert len(three._state) == 3 and np.array_equal(a, b)
+            assert np.max(np.abs(b - orc.predict(orc.LSTM(lp[0], 2), xr, off, True, 1, 3, ftc))) <= TOL
+            ens = networks.NNWithRPL(ls[0], ls[1:], None)
+            a = one.forward_lstm(ens, xr, off, ft=ftc, prior=real_priors)
+            b = three.forward_lstm(ens, xr, off, ft=ftc, prior=real_priors)
+            assert np.array_equal(a, b)
+            om = orc.NNWithRPL(orc.LSTM(lp[0], 2), [orc.LSTM(q, 2) for q in lp[1:]])
+            want = np.concatenate(orc.evaluate_posteriors(om, orc.evaluate_frontend(xr, 0, ftc), off, ap=real_priors, rnn=True))
+            assert np.max(np.abs(b - want)) <= TOL
+        finally:
+            three.close()
+    finally:
+        one.close()
+        many.close()
+
+
+def test_two_device_runner_equals_one_device(real_ft_path):
+    """The same check across two physical GPUs; skipped on a one-GPU box (run it where a multi-GPU node is available)."""
+    from nnacousticmodeling_amd import engine as eng, networks, sharding
+    if eng.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    rng = np.random.default_rng(18)
+    ft = orc.load_kaldi_feature_transform(real_ft_path)
+    x = rng.standard_normal((30001, 40)).astype(np.float32)
+    iv = rng.standard_normal((30001, 10)).astype(np.float32)
+    spec = networks.get_nn("ff", 2, [256], 1909).set_params(orc.make_mlp_params(rng, 450, 256, 2, 1909))
+    a = sharding.PosteriorRunner([0]).forward_ff(spec, x, shifts=range(-5, 6), ft=ft, ivectors=iv)
+    b = sharding.PosteriorRunner([0, 1]).forward_ff(spec, x, shifts=range(-5, 6), ft=ft, ivectors=iv)
+    assert np.array_equal(a, b)
+    ftc = orc.centre_frame_transform(ft)
+    off = orc.make_offsets(rng, 30, 5000, lo=40, hi=400)
+    ls = networks.get_nn("lstm", 2, [128], 1909).set_params(orc.make_lstm_params(rng, 40, 128, 2, 1909))
+    a = sharding.PosteriorRunner([0]).forward_lstm(ls, x[:5000], off, ft=ftc, timedelay=2)
+    b = sharding.PosteriorRunner([0, 1]).forward_lstm(ls, x[:5000], off, ft=ftc, timedelay=2)
+    assert np.array_equal(a, b)
+
+
+def test_ten_fold_ensemble_config_size(engine, real_ft_path, real_priors):
+    """BASELINE configs[4]: 10 members of the 4x1024 network on the core-test-like 57,919 frames -- evaluate's NNWithRPL
+    (master + 9 folds, logits (K*master + sum folds) / 2K, evaluate.py:35-51) and predict_folds' dev-mode mean of the
+    per-fold log-posteriors (predict_folds.py:199-220).  Sampled rows against the oracle on exactly those rows, every row a
+    normalised log-distribution, and two frame shards with halo equal to the whole file bit for bit."""
+    from nnacousticmodeling_amd._lib import AM_COMBINE_LOGITS, AM_COMBINE_LOGPOST
+    from nnacousticmodeling_amd.engine import Model, Pipeline
+    rng = np.random.default_rng(410)
+    n, K = 57919, 10
+    ft = orc.load_kaldi_feature_transform(real_ft_path)
+    x = rng.standard_normal((n, 40)).astype(np.float32)
+    plist = [orc.make_mlp_params(rng, 440, 1024, 4, 1909) for _ in range(K)]
+    models = [Model(engine, "ff", 4, q) for q in plist]
+    rows = _sample_rows(n, rng, 48)
+    feats = orc.apply_feature_transform(orc.prepare_batch(x, rows, 11), ft)
+    logits = [orc.MLP(q, 4)(feats) for q in plist]
+    mid = n // 2 + 3
+    for combine, master in ((AM_COMBINE_LOGITS, True), (AM_COMBINE_LOGPOST, False)):
+        p = Pipeline(engine)
+        p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+        p.set_members(models, has_master=master, combine=combine)
+        if master:
+            p.set_prior(real_priors)
+        y = p.forward_ff(x)
+        assert y.shape == (n, 1909) and np.all(np.isfinite(y))
+        assert np.max(np.abs(orc.logsum(y, axis=1))) <= 2e-5
+        if master:   # evaluate.py:44-50: h = K*master + sum(folds); h /= 2K  (K = number of folds), then - ap, - logsum
+            kf = K - 1
+            h = kf * logits[0]
+            for lg in logits[1:]:
+                h = h + lg
+            want = h / np.float32(2 * kf) - real_priors
+        else:        # predict_folds.py:199-220
+            want = 0
+            for lg in logits:
+                want = want + (lg - orc.logsum(lg, axis=1))
+            want = want / np.float32(K)
+        want = want - orc.logsum(want, axis=1)
+        assert np.max(np.abs(y[rows] - want)) <= TOL
+        lo = p.forward_ff(x[:mid + 5], None, mid, 0, 5)
+        hi = p.forward_ff(x[mid - 5:], None, n - mid, 5, 0)
+        assert np.array_equal(lo, y[:mid]) and np.array_equal(hi, y[mid:])
+        p.close()

@@ -34,6 +34,34 @@ def test_segmentations_match_reference_golden(engine, golden_dir, tmp_path):
         dec.close()
 
 
+def test_real_size_graph_matches_reference_golden_in_all_three_forms(engine, golden_dir):
+    """The size of the absent kaldiTri1909.img: 48 phones, 2,304 nodes, 88,294 triphones, 1909 states, eight utterances of
+    3..614 frames, two (PIP, LMW) settings.  tests/golden/viterbi_fullsize.npz holds only the seed and the segmentations the
+    REFERENCE decoder (recog_src/source/phone_recog.cpp:138-254, built from source in the build container) produced; the
+    graph and the log-posteriors are regenerated here from the seed.  All three kernel forms must reproduce them exactly."""
+    import importlib.util
+    from nnacousticmodeling_amd.phone_recog import PhoneRecog
+    spec = importlib.util.spec_from_file_location("mkvf", os.path.join(golden_dir, "make_viterbi_fullsize_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    g = np.load(os.path.join(golden_dir, "viterbi_fullsize.npz"))
+    graph, lps = mk.inputs(vo.make_graph)
+    assert list(g["shape"]) == [mk.P, mk.S, len(graph["lm"]), len(graph["biphoneIdxIn"])] and list(g["lens"]) == mk.LENS
+    offsets = np.concatenate([[0], np.cumsum(mk.LENS)])
+    lp = np.concatenate(lps)
+    gdict = dict(graph, numPhones=mk.P, numBiphones=len(graph["lm"]), numTriphones=len(graph["biphoneIdxIn"]))
+    for pi, (PIP, LMW) in enumerate(g["params"]):
+        dec = PhoneRecog(engine, gdict, float(PIP), float(LMW))
+        for form in ("frame_sync", "per_utt_compact", "per_utt_wide", "auto"):
+            dec.set_form(form)
+            got = dec.recognise(lp, offsets)
+            for u in range(len(mk.LENS)):
+                be = g["p%d_u%d_begin_end" % (pi, u)]
+                assert [(b, e) for b, e, _ in got[u]] == [(int(r[0]), int(r[1])) for r in be], (form, pi, u)
+                assert [p for _, _, p in got[u]] == list(g["p%d_u%d_phones" % (pi, u)]), (form, pi, u)
+        dec.close()
+
+
 @pytest.mark.parametrize("P,S,PIP", [(12, 300, -4.0), (9, 1909, -20.0), (10, 128, 0.0)])
 def test_larger_graphs_match_oracle(engine, P, S, PIP):
     from nnacousticmodeling_amd.phone_recog import PhoneRecog

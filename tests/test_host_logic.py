@@ -96,6 +96,47 @@ def test_sharded_lstm_equals_whole_file_oracle(real_ft_path, n_dev, timedelay):
             assert np.all(got[off[u + 1] - timedelay:off[u + 1]] == 0)
 
 
+def test_per_fold_models_are_never_confused_after_gc(real_ft_path):
+    """Regression: the per-shard model cache used id(spec) as its key; once an earlier fold's spec had been
+    collected CPython reused the address and a later fold ran with the earlier fold's weights.  Here: 12 folds with
+    different weights, a fresh NetworkSpec per fold, gc.collect() in between, every fold checked against the oracle; the
+    cache must also hold one fold at a time (the previous fold's device copy is closed)."""
+    import gc
+    rng = np.random.default_rng(11)
+    ft = orc.load_kaldi_feature_transform(real_ft_path)
+    x = rng.standard_normal((64, 40)).astype(np.float32)
+    runner = sharding.PosteriorRunner([0, 1], backend=fake_backend)
+    for fold in range(12):
+        params = orc.make_mlp_params(np.random.default_rng(100 + fold), 440, 24, 1, 39)
+        spec = networks.get_nn("ff", 1, [24], 39).set_params(params)
+        got = runner.forward_ff(spec, x, shifts=range(-5, 6), ft=ft)
+        want = orc.predict(orc.MLP(params, 1), x, None, False, 11, 0, ft)
+        assert np.max(np.abs(got - want)) < 1e-5, "fold %d computed with another fold's weights" % fold
+        for st in runner._state.values():
+            assert len(st.models) == 1 and st.models[0][0] is spec
+        del spec, params
+        gc.collect()
+
+
+def test_logical_shards_share_a_device(real_ft_path):
+    """(device, replica) pairs: several logical shards on one GPU, each with its own engine; plain ids may repeat."""
+    assert sharding._normalise_shards([0, 0, 1]) == [(0, 0), (0, 1), (1, 0)]
+    assert sharding._normalise_shards([(0, 0), (0, 2)]) == [(0, 0), (0, 2)]
+    with pytest.raises(ValueError):
+        sharding._normalise_shards([(0, 1), (0, 1)])
+    rng = np.random.default_rng(5)
+    ft = orc.load_kaldi_feature_transform(real_ft_path)
+    params = orc.make_mlp_params(rng, 440, 32, 2, 39)
+    x = rng.standard_normal((333, 40)).astype(np.float32)
+    spec = networks.get_nn("ff", 2, [32], 39).set_params(params)
+    before = len(fake_backend.created_engines)
+    runner = sharding.PosteriorRunner([(0, 0), (0, 1), (0, 2)], backend=fake_backend)
+    got = runner.forward_ff(spec, x, shifts=range(-5, 6), ft=ft)
+    assert fake_backend.created_engines[before:] .count(0) == 3   # three engines, all on device 0
+    want = orc.predict(orc.MLP(params, 2), x, None, False, 11, 0, ft)
+    assert np.max(np.abs(got - want)) < 1e-5
+
+
 # ---------------------------------------------------------------------------------------------------
 def _write_ft(path, real_ft_path):
     with open(real_ft_path) as f, open(path, "w") as g:
