@@ -152,7 +152,7 @@ def main():
             p.close()
     if args.which in ("all", "cells"):
         # the other recurrent cells of get_nn at the LSTM config's size
-        for net in (args.cell.split(",") if args.cell else ("gru", "mgrurelu", "peepholelstm")):
+        for net in (args.cell.split(",") if args.cell else ("gru", "mgrurelu", "mgrurelur", "peepholelstm")):
             if net == "peepholelstm":
                 params = orc.make_peephole_params(rng, 40, 512, 3, 1909)
                 fl = 2 * (40 * 2048 + 2 * 512 * 2048 + 3 * 512 * 2048 + 3 * 3 * 512 * 512 + 512 * 1909)
