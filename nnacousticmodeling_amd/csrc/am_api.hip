@@ -149,6 +149,11 @@ struct am_pipeline {
     int64_t n_packed = 0;
     int n_slots = 0;
     int timedelay = 0;
+    // persistent form of the LSTM stack (lstm_persist_kernel): per member the group plan + arrival table, shared step tables
+    struct PersistPlan { bool ok = false; LstmPersistArgs args{}; DevBuf cum; };
+    std::vector<PersistPlan> persist;
+    DevBuf d_nact, d_stepoff, d_sync;   // int [T], int [T + 1], unsigned [groups + 1] (arrival counters, abort flag last)
+    bool used_persist = false;
     // the recurrent launch sequence (thousands of ~2 us kernels) is replayed from a hipGraph from the 2nd run on
     int lstm_runs = 0;
     hipGraph_t graph = nullptr;
@@ -705,8 +710,9 @@ extern "C" int am_pipeline_destroy(am_pipeline* p)
     for (auto ev : p->chunk_done) (void)hipEventDestroy(ev);
     p->drop_graph();
     for (DevBuf* d : {&p->d_shifts, &p->d_add, &p->d_scale, &p->d_rplw, &p->d_rplb, &p->d_rpllb, &p->d_prior, &p->d_x, &p->d_ivec, &p->d_in, &p->d_in_s,
-                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c})
+                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c, &p->d_nact, &p->d_stepoff, &p->d_sync})
         d->release();
+    for (auto& pl : p->persist) pl.cum.release();
     am_engine* e = p->e;
     delete p;
     engine_child_gone(e);
@@ -1275,6 +1281,36 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
     AM_TRY(p->d_acc.ensure(sizeof(float) * rows_pad * m0->C_pad));
     if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(p->d_acc2.ensure(sizeof(float) * rows_pad * m0->C_pad));
     AM_TRY(p->d_out.ensure(std::max<size_t>(sizeof(float) * N * m0->C, 16)));
+    // persistent form: plan the row groups per LSTM member and upload the step / arrival tables
+    for (auto& pl : p->persist) pl.cum.release();
+    p->persist.clear();
+    p->persist.resize(p->members.size());
+    if (T > 0 && (size_t)rows_alloc * upad * sizeof(float) < ((size_t)1 << 31)) {
+        std::vector<int> nact(p->n_active.begin(), p->n_active.end()), soff(p->step_off.begin(), p->step_off.end());
+        AM_TRY(p->d_nact.ensure(sizeof(int) * nact.size()));
+        AM_TRY(p->d_stepoff.ensure(sizeof(int) * soff.size()));
+        HIP_TRY(hipMemcpyAsync(p->d_nact.p, nact.data(), sizeof(int) * nact.size(), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(p->d_stepoff.p, soff.data(), sizeof(int) * soff.size(), hipMemcpyHostToDevice, e->stream));
+        AM_TRY(p->d_sync.ensure(sizeof(unsigned) * 64));
+        std::vector<std::vector<unsigned>> cums(p->members.size());
+        for (size_t mi = 0; mi < p->members.size(); ++mi) {
+            am_model* m = p->members[mi];
+            if (m->cell != AM_CELL_LSTM) continue;
+            bool fits = m->L[0].out_pad == 4 * m->L[0].U_pad;
+            for (int l = 0; l < m->n_layers && fits; ++l) fits = m->L[l].U_pad == m->L[0].U_pad && (l == 0 || m->L[l].in_pad == m->L[l].U_pad);
+            if (!fits) continue;
+            auto& pl = p->persist[mi];
+            pl.args = LstmPersistArgs{};
+            pl.args.n_layers = m->n_layers; pl.args.U_pad = m->L[0].U_pad; pl.args.T = (int)T;
+            if (!plan_lstm_persist(pl.args, n_utts, nact.data(), nullptr)) continue;
+            cums[mi].resize(lstm_persist_cum_size(pl.args));
+            plan_lstm_persist(pl.args, n_utts, nact.data(), cums[mi].data());
+            AM_TRY(pl.cum.ensure(sizeof(unsigned) * cums[mi].size()));
+            HIP_TRY(hipMemcpyAsync(pl.cum.p, cums[mi].data(), sizeof(unsigned) * cums[mi].size(), hipMemcpyHostToDevice, e->stream));
+            pl.ok = true;
+        }
+        AM_TRY(sync_all(e));   // the staging vectors go out of scope here
+    }
     AM_TRY(sync_all(e));
     p->drop_graph();
     p->n = N; p->n_packed = NP; p->n_slots = n_utts; p->has_ivec = ivec != nullptr; p->timedelay = timedelay;
@@ -1283,6 +1319,16 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
 }
 
 static int lstm_enqueue(am_pipeline* p);
+
+// After a synchronisation: did the persistent recurrent kernel give up on a wait (lstm_persist_kernel's abort flag)?
+static int persist_check(am_pipeline* p)
+{
+    if (p->mode != 2 || !p->used_persist || !p->d_sync.p) return AM_OK;
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, p->d_sync.as<int>() + 63, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) { p->results_valid = false; return fail(AM_EHIP, "the persistent recurrent kernel timed out waiting for another workgroup; the pass is invalid (set AM_LSTM_PERSIST=0 to use the per-step kernels)"); }
+    return AM_OK;
+}
 
 extern "C" int am_lstm_run(am_pipeline* p)
 {
@@ -1396,6 +1442,8 @@ static int lstm_enqueue(am_pipeline* p)
         memcpy(&bits, &fill, sizeof(bits));
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p->d_out.p, bits, (size_t)p->n * m0->C, e->stream));
     }
+    p->used_persist = false;
+    if (p->d_sync.p) HIP_TRY(hipMemsetAsync(p->d_sync.p, 0, sizeof(unsigned) * 64, e->stream));
     GatherArgs ga{};
     ga.x = p->d_x.as<float>(); ga.ivec = p->has_ivec ? p->d_ivec.as<float>() : nullptr; ga.src = p->d_src.as<int>();
     ga.n = NP; ga.n_pad = rows_pad; ga.D = p->D;
@@ -1419,9 +1467,26 @@ static int lstm_enqueue(am_pipeline* p)
             g.epi = EPI_LINEAR; g.alpha = 1.f;
             AM_TRY(run_kernel(e, K_LSTM_UPWARD, [&] { return launch_gemm(e->stream, g); }));
         }
-        // wavefront over (layer, time): launch d runs layer l at t = d - l; chain length T + NL - 1 instead of T * NL
         float* Hall = p->d_H.as<float>();
         float* Call = p->d_c.as<float>();
+        if (p->persist[mi].ok) {
+            // the whole stack and time axis in one persistent launch (lstm_persist_kernel)
+            LstmPersistArgs pa = p->persist[mi].args;
+            for (int l = 0; l < NL; ++l) {
+                Layer& Ly = m->L[l];
+                LstmPersistLayer& s = pa.L[l];
+                s.G = l == 0 ? p->d_G.as<float>() : nullptr;
+                s.bias = Ly.b.as<float>(); s.Wup = l == 0 ? nullptr : Ly.W.as<float>(); s.Wlat = Ly.Wlat.as<float>();
+                s.Hin = l == 0 ? nullptr : Hall + (l - 1) * h_stride;
+                s.H = Hall + l * h_stride; s.Cst = Call + l * c_stride;
+            }
+            pa.n_active = p->d_nact.as<int>(); pa.step_off = p->d_stepoff.as<int>(); pa.cum = p->persist[mi].cum.as<unsigned>();
+            pa.counters = p->d_sync.as<unsigned>(); pa.abort_flag = p->d_sync.as<int>() + 63;
+            HIP_TRY(hipMemsetAsync(p->d_sync.p, 0, sizeof(unsigned) * 63, e->stream));   // the abort flag (last word) is cleared once per pass
+            AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_persist(e->stream, pa); }));
+            p->used_persist = true;
+        } else
+        // wavefront over (layer, time): launch d runs layer l at t = d - l; chain length T + NL - 1 instead of T * NL
         for (int64_t d = 0; d < T + NL - 1; ++d) {
             LstmWavefrontArgs w{};
             w.U_pad = U_pad;
@@ -1464,7 +1529,7 @@ extern "C" int am_lstm_download(am_pipeline* p, float* y)
     AM_TRY(join_streams(e));
     if (p->n > 0) HIP_TRY(hipMemcpyAsync(y, p->d_out.p, sizeof(float) * p->n * p->members[0]->C, hipMemcpyDeviceToHost, e->stream));
     AM_TRY(sync_all(e));
-    return AM_OK;
+    return persist_check(p);
 }
 
 extern "C" int am_forward_lstm(am_pipeline* p, const float* x, const float* ivec, const int64_t* offsets, int n_utts, int timedelay, float* y)
@@ -1795,5 +1860,6 @@ extern "C" int am_decode_pipeline(am_decoder* d, am_pipeline* p, const int64_t* 
     if (offsets[n_utts] != p->n) return fail(AM_EINVAL, "am_decode_pipeline: offsets cover %lld frames, the pipeline holds %lld", (long long)offsets[n_utts], (long long)p->n);
     HIP_TRY(hipSetDevice(d->e->device));
     AM_TRY(join_streams(d->e));
+    if (p->mode == 2 && p->used_persist) { AM_TRY(sync_all(d->e)); AM_TRY(persist_check(p)); }
     return decode_device(d, p->d_out.as<float>(), d->S, offsets, n_utts, seg_begin, seg_end, seg_tri, seg_count);
 }

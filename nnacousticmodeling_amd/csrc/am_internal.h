@@ -116,6 +116,36 @@ struct LstmWavefrontArgs {
 };
 hipError_t launch_lstm_wavefront(hipStream_t s, LstmWavefrontArgs& a);
 
+// The whole LSTM stack over the whole time axis in ONE persistent launch (lstm_persist_kernel): one workgroup per CU keeps
+// its slice of the weights in registers for the entire pass and exchanges h / c with the other workgroups through
+// agent-scope (sc1) stores + per-group arrival counters instead of kernel boundaries.
+struct LstmPersistLayer {
+    const float* G;      // layer 0: hoisted upward pre-activations (+bias) [NP, 4*U_pad], time-major packed; else nullptr
+    const float* bias;   // layers >= 1: [4*U_pad] gate-tiled
+    const float* Wup;    // layers >= 1: [4*U_pad, U_pad] gate-tiled rows
+    const float* Wlat;   // [4*U_pad, U_pad] gate-tiled rows
+    const float* Hin;    // layers >= 1: packed H plane of the layer below [>= NP, U_pad]
+    float* H;            // this layer's packed H plane
+    float* Cst;          // this layer's cell state [slots, U_pad]
+    int n_groups;        // row groups of this layer
+    int group0;          // index of its first group among all groups (counter index)
+};
+struct LstmPersistArgs {
+    LstmPersistLayer L[LSTM_MAX_LAYERS];
+    int n_layers, U_pad, T;
+    int n_groups_total;            // grid = n_groups_total * (U_pad / 16)
+    const int* n_active;           // device [T]
+    const int* step_off;           // device [T + 1]
+    const unsigned* cum;           // device [n_groups_total][T]: arrivals group g has made once its step t is complete
+    unsigned* counters;            // device [n_groups_total], zero before the launch
+    int* abort_flag;               // device, zero before the launch; set when a wait timed out (the pass is then invalid)
+};
+// Host-side plan: fills n_groups / group0 / n_groups_total for `n_slots` utterance slots and returns false when the
+// stack does not fit the persistent form (then the per-step kernels run).  cum_out: [n_groups_total][T] arrival targets.
+bool plan_lstm_persist(LstmPersistArgs& a, int n_slots, const int* n_active_host, unsigned* cum_out /*nullable*/);
+size_t lstm_persist_cum_size(const LstmPersistArgs& a);   // entries of `cum`
+hipError_t launch_lstm_persist(hipStream_t s, const LstmPersistArgs& a);
+
 // Recurrent cells other than L.LSTM (GRU / MGRU / peephole LSTM): one phase of one wavefront tick, see rec_step_kernel.
 enum RecEpilogue {
     REC_MGRU = 0,    // 2 gates (z, h~):   h = z*act(h~) + (1-z)*h_prev                               (MGRU.py:67-85, no reset gate)

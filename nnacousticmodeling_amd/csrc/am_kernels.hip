@@ -1146,6 +1146,332 @@ __global__ __launch_bounds__(512) void lstm_thin_kernel(const LstmWavefrontArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The whole stack, the whole time axis, ONE launch ("persistent" form; replaces the T + L - 1 dependent launches above when
+// the stack fits: U_pad 256 or 512, at most 256 workgroups).
+//
+// Why: a dependent launch costs ~2 us of boundary plus a cold start -- L2 contents do not survive it, so every step
+// re-fetched the whole weight set (22-39 MB per launch) and paid a memory round trip before its first MFMA; at 192 rows a
+// step took 26.7 us against 13.7 us of MFMA time.  Here nothing is re-fetched: a workgroup = (layer, row group, 16-unit
+// tile) loads its 64 gate columns x K of weights ONCE into registers (wave = gate x K half: 16 columns x K/2 = K/8 VGPRs,
+// 128 at K = 1024) and then walks the time axis.  Per step only the activation rows move: h through HBM/L2 with
+// write-through (sc1) stores and L1-bypassing (sc1) loads, handed over by per-group arrival counters (one agent-scope
+// atomic add per workgroup and step, one lane polling; MI355X_MICROARCH.md, inter-workgroup visibility, first row of the
+// measured hand-off table).  The execution is dataflow, not lock-step:
+//   step t of (layer l, group g) = [wait: layer l-1 has finished step t]   upward product   h_{l-1}[t] . Wup^T
+//                                  [wait: layer l   has finished step t-1] lateral product  h_l[t-1]   . Wlat^T
+//                                  gates, c, h  ->  sc1 stores  ->  vmcnt(0), barrier, counter += 1
+// so the upward half of step t runs in the shadow of the other workgroups' step t-1, lower layers run ahead freely (every
+// layer has its own time-major H plane, nothing is overwritten), and a step's cost approaches its MFMA time.
+// Row groups are re-cut EVERY step: with `tiles` 16-row tiles active, group g of NG takes tiles [g q, g q + q), q =
+// ceil(tiles / NG) -- all workgroups of a layer stay busy while utterances end (the cell state therefore travels through
+// memory like h).  Rows past n_active[t] are never loaded: in the packed layout they alias rows of step t+1 that another
+// XCD may not have written yet, and a line fetched early would stay stale in this XCD's L2.
+// Same summation order as the per-step kernels: per K half, 64-k chains from zero folded in k order (upward batches, then
+// lateral), (half 0 + half 1) + G/bias -- a frame's posteriors do not depend on the form that computed them.
+// Every wait is bounded (2 s of the 100 MHz counter): a timeout raises `abort_flag`, every workgroup leaves, the host
+// reports an error instead of hanging the GPU.
+// ---------------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int LSTM_P_TIMEOUT = 200000000;   // ticks of s_memrealtime (100 MHz)
+
+__device__ __forceinline__ unsigned ld_agent_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ f32x4 ld_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16 /* sc1 */));
+}
+
+// Wave 0, lane j < n polls counter first + j until it reaches cum[(first + j) * T + tcol]; then the workgroup's barrier.
+// Returns false (all threads) when the pass has been aborted.
+__device__ __forceinline__ bool persist_wait(const LstmPersistArgs& a, int first, int n, int tcol, int* s_flag)
+{
+    if (threadIdx.x < 64) {
+        bool ok = true;
+        if ((int)threadIdx.x < n) {
+            const unsigned target = a.cum[(size_t)(first + threadIdx.x) * a.T + tcol];
+            const unsigned* c = a.counters + first + threadIdx.x;
+            if (ld_agent_u32(c) < target) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                int it = 0;
+                while (ld_agent_u32(c) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++it & 63) == 0 && (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                                            __builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)LSTM_P_TIMEOUT)) { ok = false; break; }
+                }
+            }
+        }
+        if (!ok) { __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *s_flag = 1; }
+    }
+    __syncthreads();
+    return *s_flag == 0;
+}
+
+// NB batches of 128 k of one product: A rows [row_base, row_base + 16 NT) of `src` (only the first rows_valid are loaded)
+// times the resident weight fragments w; tiles staged through the double-buffered LDS tile as in lstm_wreg_body.
+template <int NB, int NT>
+__device__ __forceinline__ void persist_phase(__amdgpu_buffer_rsrc_t src, unsigned row_base, int rows_valid, int U_pad, const f32x4 (&w)[NB][LSTM_KS],
+                                              f32x4 (&acc)[NT], float* sA0, float* sA1, int tid, int l15, int lq, int kh)
+{
+    f32x4 av[2][NT];
+    auto load_a = [&](int b, f32x4 (&dst)[NT]) {
+#pragma unroll
+        for (int e = 0; e < NT; ++e) {
+            const int idx = tid + 512 * e, r = idx >> 5, c4 = idx & 31;
+            dst[e] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (r < rows_valid) dst[e] = ld_sc1_b128(src, ((row_base + r) * (unsigned)U_pad + (unsigned)(b * LSTM_KB + 4 * c4)) * 4u);
+        }
+    };
+    load_a(0, av[0]);
+    if (NB > 1) load_a(1, av[1]);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        float* sA = (b & 1) ? sA1 : sA0;
+#pragma unroll
+        for (int e = 0; e < NT; ++e) {
+            const int idx = tid + 512 * e, r = idx >> 5, c4 = idx & 31;
+            *(f32x4*)(sA + r * LSTM_LDA + 4 * c4) = av[b & 1][e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // tile b is complete; everyone left tile b-2 (same buffer) before barrier b-1
+        if (b + 2 < NB) load_a(b + 2, av[b & 1]);
+        const float* sa = sA + l15 * LSTM_LDA + kh * (LSTM_KB / 2) + 4 * lq;
+        f32x4 pb[NT];
+#pragma unroll
+        for (int r = 0; r < NT; ++r) pb[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < LSTM_KS; ++s) {
+            f32x4 af[NT];
+#pragma unroll
+            for (int r = 0; r < NT; ++r) af[r] = *(const f32x4*)(sa + r * 16 * LSTM_LDA + 16 * s);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < NT; ++r) pb[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][j], w[b][s][j], pb[r], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < NT; ++r) acc[r] += pb[r];
+    }
+    __syncthreads();   // every fragment read is done: the tiles may be rewritten (next product / gate exchange)
+}
+
+template <int NBU, int NBL, int NT>
+__device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const LstmPersistLayer& Ly, int li, int gidx, int ut, int t, int n_act, int row0,
+                                             const f32x4 (&wu)[NBU ? NBU : 1][LSTM_KS], const f32x4 (&wl)[NBL][LSTM_KS], const float (&bias4)[4],
+                                             float* smem, int tile_rows, int* s_flag)
+{
+    constexpr int ROWS = NT * 16;
+    constexpr int EP = (ROWS * 16 + 511) / 512;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gate = wave & 3, kh = wave >> 2;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int U_pad = a.U_pad, ldg = 4 * U_pad;
+    const int rows_valid = n_act - row0;                       // > 0
+    const unsigned r_t = (unsigned)(a.step_off[t] + row0);      // packed row of slot row0 at step t
+    float* sA0 = smem;
+    float* sA1 = smem + tile_rows * LSTM_LDA;
+
+    float gpre[EP][4];
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+        const int idx = tid + 512 * e, erow = idx >> 4, eu = idx & 15;
+        const bool live = erow < ROWS && erow < rows_valid;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            gpre[e][k] = NBU ? bias4[k] : (live ? Ly.G[(size_t)(r_t + erow) * ldg + ut * 64 + k * 16 + eu] : 0.0f);
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int r = 0; r < NT; ++r) acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    if (NBU) {   // upward product: needs step t of the layer below (which runs ahead: normally no wait at all)
+        if (!persist_wait(a, a.L[li - 1].group0, a.L[li - 1].n_groups, t, s_flag)) return false;
+        const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.Hin, 0, 0x7fffffff, 0x00020000);
+        persist_phase<NBU ? NBU : 1, NT>(src, r_t, rows_valid, U_pad, wu, acc, sA0, sA1, tid, l15, lq, kh);
+    }
+    float cprev[EP];
+#pragma unroll
+    for (int e = 0; e < EP; ++e) cprev[e] = 0.0f;
+    if (t > 0) {  // lateral product: needs step t-1 of every group of this layer (the rows were cut differently then)
+        if (!persist_wait(a, Ly.group0, Ly.n_groups, t - 1, s_flag)) return false;
+#pragma unroll
+        for (int e = 0; e < EP; ++e) {
+            const int idx = tid + 512 * e, erow = idx >> 4, eu = idx & 15;
+            if (erow < ROWS && erow < rows_valid)
+                cprev[e] = __hip_atomic_load(Ly.Cst + (size_t)(row0 + erow) * U_pad + ut * 16 + eu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.H, 0, 0x7fffffff, 0x00020000);
+        persist_phase<NBL, NT>(src, (unsigned)(a.step_off[t - 1] + row0), rows_valid, U_pad, wl, acc, sA0, sA1, tid, l15, lq, kh);
+    }
+    float* sg = smem;   // [kh][gate][ROWS][17], aliases the A tiles (both products end with a barrier)
+#pragma unroll
+    for (int r = 0; r < NT; ++r)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            sg[((kh * 4 + gate) * ROWS + r * 16 + lq * 4 + reg) * 17 + l15] = acc[r][reg];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+        const int idx = tid + 512 * e, erow = idx >> 4, eu = idx & 15;
+        if (erow < ROWS && erow < rows_valid) {
+            float pre[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                pre[k] = (sg[((0 * 4 + k) * ROWS + erow) * 17 + eu] + sg[((1 * 4 + k) * ROWS + erow) * 17 + eu]) + gpre[e][k];
+            const float ga = tanhf(pre[0]);
+            const float gi = am_sigmoid(pre[1]);
+            const float gf = am_sigmoid(pre[2]);
+            const float go = am_sigmoid(pre[3]);
+            const float ai = ga * gi;
+            const float fc = gf * cprev[e];
+            const float c = ai + fc;
+            __hip_atomic_store(Ly.Cst + (size_t)(row0 + erow) * U_pad + ut * 16 + eu, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(Ly.H + (size_t)(r_t + erow) * U_pad + ut * 16 + eu, go * tanhf(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // publish: every storing wave drains its stores, the workgroup meets, ONE lane signals for all of them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(a.counters + gidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
+template <int NBU, int NBL, int NTMAX>
+__device__ __forceinline__ void persist_body(const LstmPersistArgs& a, const LstmPersistLayer& Ly, int li, int gidx, int ut, float* smem, int* s_flag)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gate = wave & 3, kh = wave >> 2;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int U_pad = a.U_pad;
+    const int g = gidx - Ly.group0, NG = Ly.n_groups;
+    // the resident weights: this wave's 16 gate columns x its half of every 128-k batch
+    f32x4 wl[NBL][LSTM_KS], wu[NBU ? NBU : 1][LSTM_KS];
+    {
+        const size_t wrow = (size_t)(ut * 64 + gate * 16 + l15) * U_pad + kh * (LSTM_KB / 2) + 4 * lq;
+#pragma unroll
+        for (int b = 0; b < NBL; ++b)
+#pragma unroll
+            for (int s = 0; s < LSTM_KS; ++s) wl[b][s] = *(const f32x4*)(Ly.Wlat + wrow + b * LSTM_KB + 16 * s);
+        if (NBU) {
+#pragma unroll
+            for (int b = 0; b < (NBU ? NBU : 1); ++b)
+#pragma unroll
+                for (int s = 0; s < LSTM_KS; ++s) wu[b][s] = *(const f32x4*)(Ly.Wup + wrow + b * LSTM_KB + 16 * s);
+        }
+    }
+    float bias4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (NBU) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bias4[k] = Ly.bias[ut * 64 + k * 16 + (tid & 15)];
+    }
+    for (int t = 0; t < a.T; ++t) {
+        const int n_act = a.n_active[t];
+        const int tiles = (n_act + 15) >> 4;
+        if (tiles <= 0) break;
+        const int q = (tiles + NG - 1) / NG;            // <= NTMAX (host plan)
+        const int tile0 = g * q;
+        int nt = tiles - tile0;
+        if (nt > q) nt = q;
+        if (nt <= 0) continue;                          // nothing for this group at this step (the host's arrival table knows)
+        bool ok = true;
+        const int row0 = tile0 * 16;
+        switch (nt) {
+        case 1: ok = persist_step<NBU, NBL, 1>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, bias4, smem, NTMAX * 16, s_flag); break;
+        case 2: ok = persist_step<NBU, NBL, 2>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, bias4, smem, NTMAX * 16, s_flag); break;
+        case 3: ok = persist_step<NBU, NBL, 3>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, bias4, smem, NTMAX * 16, s_flag); break;
+        case 4: ok = persist_step<NBU, NBL, 4>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, bias4, smem, NTMAX * 16, s_flag); break;
+        case 5: if (NTMAX >= 5) ok = persist_step<NBU, NBL, NTMAX >= 5 ? 5 : 1>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, bias4, smem, NTMAX * 16, s_flag); break;
+        case 6: if (NTMAX >= 6) ok = persist_step<NBU, NBL, NTMAX >= 6 ? 6 : 1>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, bias4, smem, NTMAX * 16, s_flag); break;
+        default: break;
+        }
+        if (!ok) return;
+    }
+}
+
+constexpr int lstm_persist_ntmax(int nb, bool upward) { return (upward ? 2 * nb : nb) >= 8 ? 4 : 6; }   // by the register budget: K/8 VGPRs of weights
+constexpr size_t LSTM_PERSIST_LDS = 2 * 96 * LSTM_LDA * sizeof(float);   // two 96-row tiles; the gate exchange aliases them
+
+template <int NB>
+__global__ __launch_bounds__(512, 2) void lstm_persist_kernel(const LstmPersistArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float persist_smem[];
+    __shared__ int s_flag;
+    if (threadIdx.x == 0) s_flag = 0;
+    __syncthreads();
+    // role: blocks b and b + n_groups_total share a group's neighbour tiles; b % n_groups_total = group, so with 8 groups the
+    // 32 workgroups of a group sit on one XCD under round-robin placement (speed only)
+    const int gidx = blockIdx.x % a.n_groups_total, ut = blockIdx.x / a.n_groups_total;
+    int li = 0;
+#pragma unroll
+    for (int l = 1; l < LSTM_MAX_LAYERS; ++l) if (l < a.n_layers && gidx >= a.L[l].group0) li = l;
+    const LstmPersistLayer& Ly = a.L[li];
+    if (li > 0) persist_body<NB, NB, lstm_persist_ntmax(NB, true)>(a, Ly, li, gidx, ut, persist_smem, &s_flag);
+    else persist_body<0, NB, lstm_persist_ntmax(NB, false)>(a, Ly, li, gidx, ut, persist_smem, &s_flag);
+}
+
+static int lstm_persist_mode()
+{
+    static int mode = -1;   // AM_LSTM_PERSIST=0 keeps the per-step kernels (A/B measurements)
+    if (mode < 0) { const char* v = getenv("AM_LSTM_PERSIST"); mode = v ? atoi(v) : 1; }
+    return mode;
+}
+
+bool plan_lstm_persist(LstmPersistArgs& a, int n_slots, const int* n_active, unsigned* cum_out)
+{
+    if (!lstm_persist_mode()) return false;
+    if (a.n_layers < 1 || a.n_layers > LSTM_MAX_LAYERS || a.T <= 0 || n_slots <= 0) return false;
+    if (a.U_pad != 256 && a.U_pad != 512) return false;
+    const int nb = a.U_pad / LSTM_KB, tpg = a.U_pad / 16, budget = 256 / tpg;   // groups the chip can hold at one workgroup per CU
+    const int tiles0 = (n_slots + 15) / 16;
+    int ng[LSTM_MAX_LAYERS], total = 0;
+    for (int l = 0; l < a.n_layers; ++l) {
+        const int ntmax = lstm_persist_ntmax(nb, l > 0);
+        ng[l] = (tiles0 + ntmax - 1) / ntmax;
+        total += ng[l];
+    }
+    if (total > budget) return false;
+    // spare workgroups go, one group at a time, to the layer whose costliest group is the heaviest (k-batches x tiles)
+    for (;;) {
+        if (total >= budget) break;
+        int best = -1; long best_w = 0;
+        for (int l = 0; l < a.n_layers; ++l) {
+            if (ng[l] >= tiles0) continue;
+            const long wk = (long)(l > 0 ? 2 * nb : nb) * ((tiles0 + ng[l] - 1) / ng[l]);
+            if (wk > best_w) { best_w = wk; best = l; }
+        }
+        if (best < 0) break;
+        ++ng[best]; ++total;
+    }
+    int g0 = 0;
+    for (int l = 0; l < a.n_layers; ++l) { a.L[l].n_groups = ng[l]; a.L[l].group0 = g0; g0 += ng[l]; }
+    a.n_groups_total = total;
+    if (cum_out) {
+        for (int l = 0; l < a.n_layers; ++l)
+            for (int g = 0; g < ng[l]; ++g) {
+                unsigned* row = cum_out + (size_t)(a.L[l].group0 + g) * a.T;
+                unsigned c = 0;
+                for (int t = 0; t < a.T; ++t) {
+                    const int tiles = (n_active[t] + 15) / 16, q = (tiles + ng[l] - 1) / ng[l];
+                    if (tiles > 0 && g * q < tiles) c += (unsigned)tpg;
+                    row[t] = c;
+                }
+            }
+    }
+    return true;
+}
+
+size_t lstm_persist_cum_size(const LstmPersistArgs& a) { return (size_t)a.n_groups_total * a.T; }
+
+hipError_t launch_lstm_persist(hipStream_t s, const LstmPersistArgs& a)
+{
+    const int grid = a.n_groups_total * (a.U_pad / 16);
+    if (grid <= 0 || grid > 256) return hipErrorInvalidValue;
+    if (a.U_pad == 512) hipLaunchKernelGGL(lstm_persist_kernel<4>, dim3(grid), dim3(512), LSTM_PERSIST_LDS, s, a);
+    else if (a.U_pad == 256) hipLaunchKernelGGL(lstm_persist_kernel<2>, dim3(grid), dim3(512), LSTM_PERSIST_LDS, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 constexpr size_t LSTM_THIN_LDS_MAX = 72 * 1024;   // two blocks per CU stay co-resident
 static int lstm_wreg_mode()
 {
@@ -1157,6 +1483,10 @@ static int lstm_wreg_mode()
 hipError_t init_lstm_kernels()
 {
     hipError_t we = hipFuncSetAttribute((const void*)lstm_wreg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_WREG_LDS);
+    if (we != hipSuccess) return we;
+    we = hipFuncSetAttribute((const void*)lstm_persist_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_PERSIST_LDS);
+    if (we != hipSuccess) return we;
+    we = hipFuncSetAttribute((const void*)lstm_persist_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_PERSIST_LDS);
     if (we != hipSuccess) return we;
     we = hipFuncSetAttribute((const void*)lstm_wreg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_WREG_PAIR_LDS);
     if (we != hipSuccess) return we;
