@@ -186,6 +186,11 @@ int am_lstm_download(am_pipeline* p, float* y);
 int am_forward_lstm(am_pipeline* p, const float* x, const float* ivec, const int64_t* offsets, int n_utts,
                     int timedelay, float* y);
 
+/* Diagnostic (AM_LSTM_STAMPS=1 in the environment): the timeline of the last persistent recurrent launch, 8 stamps of the
+ * GPU's 100 MHz counter per (row group, time step): step start, after the upward wait / product, after the lateral wait /
+ * product, stores issued, published.  out: [n_groups][n_steps][8] or NULL to query the sizes. */
+int am_lstm_stamps(am_pipeline* p, unsigned long long* out, int64_t capacity, int* n_groups, int* n_steps);
+
 /* number of frames / classes of the resident output (after *_upload) */
 int am_pipeline_output_shape(am_pipeline* p, int64_t* n, int* c);
 

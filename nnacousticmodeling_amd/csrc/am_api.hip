@@ -150,9 +150,17 @@ struct am_pipeline {
     int n_slots = 0;
     int timedelay = 0;
     // persistent form of the LSTM stack (lstm_persist_kernel): per member the group plan + arrival table, shared step tables
-    struct PersistPlan { bool ok = false; LstmPersistArgs args{}; DevBuf cum; };
+    struct PersistPlan {
+        int form = 0;                       // 0 per-step kernels, 1 lstm_persist_kernel, 2 lstm_persist2_kernel
+        LstmPersistArgs args{}; DevBuf cum; // form 1
+        std::vector<LstmP2Args> chunks;     // form 2: one launch per chunk of utterance slots
+        std::vector<DevBuf> cums;
+        void release() { cum.release(); for (auto& c : cums) c.release(); cums.clear(); chunks.clear(); form = 0; }
+    };
     std::vector<PersistPlan> persist;
     DevBuf d_nact, d_stepoff, d_sync;   // int [T], int [T + 1], unsigned [groups + 1] (arrival counters, abort flag last)
+    DevBuf d_stamps;                    // AM_LSTM_STAMPS=1: timeline of the last member's persistent launch (am_lstm_stamps)
+    int stamps_groups = 0, stamps_T = 0;
     bool used_persist = false;
     // the recurrent launch sequence (thousands of ~2 us kernels) is replayed from a hipGraph from the 2nd run on
     int lstm_runs = 0;
@@ -710,9 +718,9 @@ extern "C" int am_pipeline_destroy(am_pipeline* p)
     for (auto ev : p->chunk_done) (void)hipEventDestroy(ev);
     p->drop_graph();
     for (DevBuf* d : {&p->d_shifts, &p->d_add, &p->d_scale, &p->d_rplw, &p->d_rplb, &p->d_rpllb, &p->d_prior, &p->d_x, &p->d_ivec, &p->d_in, &p->d_in_s,
-                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c, &p->d_nact, &p->d_stepoff, &p->d_sync})
+                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c, &p->d_nact, &p->d_stepoff, &p->d_sync, &p->d_stamps})
         d->release();
-    for (auto& pl : p->persist) pl.cum.release();
+    for (auto& pl : p->persist) pl.release();
     am_engine* e = p->e;
     delete p;
     engine_child_gone(e);
@@ -1281,18 +1289,20 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
     AM_TRY(p->d_acc.ensure(sizeof(float) * rows_pad * m0->C_pad));
     if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(p->d_acc2.ensure(sizeof(float) * rows_pad * m0->C_pad));
     AM_TRY(p->d_out.ensure(std::max<size_t>(sizeof(float) * N * m0->C, 16)));
-    // persistent form: plan the row groups per LSTM member and upload the step / arrival tables
-    for (auto& pl : p->persist) pl.cum.release();
+    // persistent forms: plan the row groups per LSTM member and upload the step / arrival tables
+    for (auto& pl : p->persist) pl.release();
     p->persist.clear();
     p->persist.resize(p->members.size());
-    if (T > 0 && (size_t)rows_alloc * upad * sizeof(float) < ((size_t)1 << 31)) {
+    const int pmode = lstm_persist_mode();
+    if (pmode && T > 0 && (size_t)rows_alloc * gw * sizeof(float) < ((size_t)1 << 31)) {
         std::vector<int> nact(p->n_active.begin(), p->n_active.end()), soff(p->step_off.begin(), p->step_off.end());
         AM_TRY(p->d_nact.ensure(sizeof(int) * nact.size()));
         AM_TRY(p->d_stepoff.ensure(sizeof(int) * soff.size()));
         HIP_TRY(hipMemcpyAsync(p->d_nact.p, nact.data(), sizeof(int) * nact.size(), hipMemcpyHostToDevice, e->stream));
         HIP_TRY(hipMemcpyAsync(p->d_stepoff.p, soff.data(), sizeof(int) * soff.size(), hipMemcpyHostToDevice, e->stream));
         AM_TRY(p->d_sync.ensure(sizeof(unsigned) * 64));
-        std::vector<std::vector<unsigned>> cums(p->members.size());
+        std::vector<std::vector<unsigned>> staging;   // alive until the copies below have been synchronised
+        int g_planes = 1;
         for (size_t mi = 0; mi < p->members.size(); ++mi) {
             am_model* m = p->members[mi];
             if (m->cell != AM_CELL_LSTM) continue;
@@ -1300,15 +1310,35 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
             for (int l = 0; l < m->n_layers && fits; ++l) fits = m->L[l].U_pad == m->L[0].U_pad && (l == 0 || m->L[l].in_pad == m->L[l].U_pad);
             if (!fits) continue;
             auto& pl = p->persist[mi];
+            const int U_pad = m->L[0].U_pad;
+            const int cap = pmode >= 2 ? lstm_persist2_capacity(U_pad, m->n_layers) : 0;
+            if (cap > 0) {
+                // split form: chunks of `cap` utterance slots, one launch each (utterances are independent)
+                bool ok = true;
+                for (int base = 0; base < n_utts && ok; base += cap) {
+                    LstmP2Args a2{};
+                    a2.n_layers = m->n_layers; a2.U_pad = U_pad; a2.T = (int)T; a2.slot_base = base; a2.slot_cap = std::min(cap, n_utts - base);
+                    if (!plan_lstm_persist2(a2, a2.slot_cap, nact.data(), nullptr)) { ok = false; break; }
+                    staging.emplace_back((size_t)a2.n_groups * T);
+                    plan_lstm_persist2(a2, a2.slot_cap, nact.data(), staging.back().data());
+                    pl.cums.emplace_back();
+                    AM_TRY(pl.cums.back().ensure(sizeof(unsigned) * staging.back().size()));
+                    HIP_TRY(hipMemcpyAsync(pl.cums.back().p, staging.back().data(), sizeof(unsigned) * staging.back().size(), hipMemcpyHostToDevice, e->stream));
+                    pl.chunks.push_back(a2);
+                }
+                if (ok) { pl.form = 2; g_planes = std::max(g_planes, m->n_layers); continue; }
+                pl.release();
+            }
             pl.args = LstmPersistArgs{};
-            pl.args.n_layers = m->n_layers; pl.args.U_pad = m->L[0].U_pad; pl.args.T = (int)T;
+            pl.args.n_layers = m->n_layers; pl.args.U_pad = U_pad; pl.args.T = (int)T;
             if (!plan_lstm_persist(pl.args, n_utts, nact.data(), nullptr)) continue;
-            cums[mi].resize(lstm_persist_cum_size(pl.args));
-            plan_lstm_persist(pl.args, n_utts, nact.data(), cums[mi].data());
-            AM_TRY(pl.cum.ensure(sizeof(unsigned) * cums[mi].size()));
-            HIP_TRY(hipMemcpyAsync(pl.cum.p, cums[mi].data(), sizeof(unsigned) * cums[mi].size(), hipMemcpyHostToDevice, e->stream));
-            pl.ok = true;
+            staging.emplace_back(lstm_persist_cum_size(pl.args));
+            plan_lstm_persist(pl.args, n_utts, nact.data(), staging.back().data());
+            AM_TRY(pl.cum.ensure(sizeof(unsigned) * staging.back().size()));
+            HIP_TRY(hipMemcpyAsync(pl.cum.p, staging.back().data(), sizeof(unsigned) * staging.back().size(), hipMemcpyHostToDevice, e->stream));
+            pl.form = 1;
         }
+        if (g_planes > 1) AM_TRY(p->d_G.ensure(sizeof(float) * rows_alloc * gw * g_planes));   // one G plane per layer (split form)
         AM_TRY(sync_all(e));   // the staging vectors go out of scope here
     }
     AM_TRY(sync_all(e));
@@ -1469,7 +1499,35 @@ static int lstm_enqueue(am_pipeline* p)
         }
         float* Hall = p->d_H.as<float>();
         float* Call = p->d_c.as<float>();
-        if (p->persist[mi].ok) {
+        if (p->persist[mi].form == 2) {
+            // split persistent form (lstm_persist2_kernel): one launch per chunk of utterance slots
+            static const bool want_stamps = env_int("AM_LSTM_STAMPS", 0) != 0;
+            const size_t g_stride = (size_t)(rows_pad + GEMM_BM) * m->L[0].out_pad;
+            for (size_t ci = 0; ci < p->persist[mi].chunks.size(); ++ci) {
+                LstmP2Args pa = p->persist[mi].chunks[ci];
+                for (int l = 0; l < NL; ++l) {
+                    Layer& Ly = m->L[l];
+                    LstmP2Layer& s = pa.L[l];
+                    s.G = p->d_G.as<float>() + l * g_stride;
+                    s.bias = Ly.b.as<float>(); s.Wup = l == 0 ? nullptr : Ly.W.as<float>(); s.Wlat = Ly.Wlat.as<float>();
+                    s.H = Hall + l * h_stride; s.Cst = Call + l * c_stride;
+                }
+                pa.n_active = p->d_nact.as<int>(); pa.step_off = p->d_stepoff.as<int>(); pa.cum = p->persist[mi].cums[ci].as<unsigned>();
+                pa.counters = p->d_sync.as<unsigned>(); pa.abort_flag = p->d_sync.as<int>() + 63;
+                static const bool skip_u = env_int("AM_P2_SKIP_U", 0) != 0;
+                pa.debug_skip_upward = skip_u ? 1 : 0;
+                if (want_stamps && ci == 0) {
+                    const size_t bytes = sizeof(unsigned long long) * 8 * (size_t)pa.n_groups * pa.T;
+                    AM_TRY(p->d_stamps.ensure(bytes));
+                    HIP_TRY(hipMemsetAsync(p->d_stamps.p, 0, bytes, e->stream));
+                    pa.stamps = p->d_stamps.as<unsigned long long>();
+                    p->stamps_groups = pa.n_groups; p->stamps_T = pa.T;
+                }
+                HIP_TRY(hipMemsetAsync(p->d_sync.p, 0, sizeof(unsigned) * 63, e->stream));
+                AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_persist2(e->stream, pa); }));
+            }
+            p->used_persist = true;
+        } else if (p->persist[mi].form == 1) {
             // the whole stack and time axis in one persistent launch (lstm_persist_kernel)
             LstmPersistArgs pa = p->persist[mi].args;
             for (int l = 0; l < NL; ++l) {
@@ -1482,6 +1540,14 @@ static int lstm_enqueue(am_pipeline* p)
             }
             pa.n_active = p->d_nact.as<int>(); pa.step_off = p->d_stepoff.as<int>(); pa.cum = p->persist[mi].cum.as<unsigned>();
             pa.counters = p->d_sync.as<unsigned>(); pa.abort_flag = p->d_sync.as<int>() + 63;
+            static const bool want_stamps = env_int("AM_LSTM_STAMPS", 0) != 0;
+            if (want_stamps) {
+                const size_t bytes = sizeof(unsigned long long) * 8 * (size_t)pa.n_groups_total * pa.T;
+                AM_TRY(p->d_stamps.ensure(bytes));
+                HIP_TRY(hipMemsetAsync(p->d_stamps.p, 0, bytes, e->stream));
+                pa.stamps = p->d_stamps.as<unsigned long long>();
+                p->stamps_groups = pa.n_groups_total; p->stamps_T = pa.T;
+            }
             HIP_TRY(hipMemsetAsync(p->d_sync.p, 0, sizeof(unsigned) * 63, e->stream));   // the abort flag (last word) is cleared once per pass
             AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_persist(e->stream, pa); }));
             p->used_persist = true;
@@ -1530,6 +1596,19 @@ extern "C" int am_lstm_download(am_pipeline* p, float* y)
     if (p->n > 0) HIP_TRY(hipMemcpyAsync(y, p->d_out.p, sizeof(float) * p->n * p->members[0]->C, hipMemcpyDeviceToHost, e->stream));
     AM_TRY(sync_all(e));
     return persist_check(p);
+}
+
+extern "C" int am_lstm_stamps(am_pipeline* p, unsigned long long* out, int64_t capacity, int* n_groups, int* n_steps)
+{
+    if (!p || !n_groups || !n_steps) return fail(AM_EINVAL, "am_lstm_stamps: bad argument");
+    *n_groups = p->stamps_groups; *n_steps = p->stamps_T;
+    const int64_t need = (int64_t)8 * p->stamps_groups * p->stamps_T;
+    if (!out || need == 0) return AM_OK;
+    if (capacity < need) return fail(AM_EINVAL, "am_lstm_stamps: buffer too small");
+    HIP_TRY(hipSetDevice(p->e->device));
+    AM_TRY(sync_all(p->e));
+    HIP_TRY(hipMemcpy(out, p->d_stamps.p, sizeof(unsigned long long) * need, hipMemcpyDeviceToHost));
+    return AM_OK;
 }
 
 extern "C" int am_forward_lstm(am_pipeline* p, const float* x, const float* ivec, const int64_t* offsets, int n_utts, int timedelay, float* y)

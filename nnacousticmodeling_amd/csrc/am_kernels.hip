@@ -25,6 +25,31 @@ __device__ __forceinline__ float am_activate(float v, int act) {
     return tanhf(v);
 }
 
+// Gate math of the recurrent cells.  libm's tanhf costs ~60 instructions; an LSTM step evaluates five of them per unit and
+// row, which was 2 of the 23 us of a 192-row step.  tanh(x) = 1 - 2 / (exp(2|x|) + 1) on the hardware exp2 / rcp for
+// |x| >= 0.25 and an odd polynomial below: max abs error 1.1e-7 over [-12, 12] (numpy's float32 tanh: 6e-8), ~1/6 of the
+// instructions.  sigmoid keeps Chainer's CPU form tanh(x/2)/2 + 1/2.  Every recurrent kernel uses these two, so a frame's
+// posteriors do not depend on the kernel form that computed them.
+__device__ __forceinline__ float am_tanh_rec(float x)
+{
+    const float ax = fabsf(x);
+    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);   // exp(2|x|)
+    const float r = __builtin_amdgcn_rcpf(e + 1.0f);
+    const float t = fmaf(-2.0f, r, 1.0f);
+    const float x2 = x * x;
+    float p = fmaf(-17.0f / 315.0f, x2, 2.0f / 15.0f);
+    p = fmaf(p, x2, -1.0f / 3.0f);
+    p = p * x2;
+    const float poly = fmaf(ax, p, ax);
+    return copysignf(ax < 0.25f ? poly : t, x);
+}
+__device__ __forceinline__ float am_sigmoid_rec(float x) { return am_tanh_rec(x * 0.5f) * 0.5f + 0.5f; }
+__device__ __forceinline__ float am_activate_rec(float v, int act) {
+    if (act == 0) return fmaxf(v, 0.0f);
+    if (act == 1) return am_sigmoid_rec(v);
+    return am_tanh_rec(v);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Linear layer:  C[M,N] = epi(A[M,K] * W[N,K]^T + bias[N])   -- "NT" GEMM, both operands K-contiguous.
 //
@@ -850,16 +875,16 @@ __global__ __launch_bounds__(512, 4) void lstm_wavefront_kernel(const LstmWavefr
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 pre[k] = (sg[((0 * 4 + k) * LSTM_RB + erow) * 17 + eu] + sg[((1 * 4 + k) * LSTM_RB + erow) * 17 + eu]) + gpre[e][k];
-            const float a = tanhf(pre[0]);
-            const float i = am_sigmoid(pre[1]);
-            const float f = am_sigmoid(pre[2]);
-            const float o = am_sigmoid(pre[3]);
+            const float a = am_tanh_rec(pre[0]);
+            const float i = am_sigmoid_rec(pre[1]);
+            const float f = am_sigmoid_rec(pre[2]);
+            const float o = am_sigmoid_rec(pre[3]);
             const float ai = a * i;
             const float fc = f * cprev[e];
             const float c = ai + fc;
             const size_t cidx = (size_t)slot * U_pad + ut * 16 + eu;
             Ls.Cst[cidx] = c;
-            Ls.Hout[cidx] = o * tanhf(c);
+            Ls.Hout[cidx] = o * am_tanh_rec(c);
         }
     }
 }
@@ -986,16 +1011,16 @@ __device__ __forceinline__ void lstm_wreg_body(const LstmLayerStep& Ls, int U_pa
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 pre[k] = (sg[((0 * 4 + k) * ROWS + erow) * 17 + eu] + sg[((1 * 4 + k) * ROWS + erow) * 17 + eu]) + gpre[e][k];
-            const float a = tanhf(pre[0]);
-            const float i = am_sigmoid(pre[1]);
-            const float f = am_sigmoid(pre[2]);
-            const float o = am_sigmoid(pre[3]);
+            const float a = am_tanh_rec(pre[0]);
+            const float i = am_sigmoid_rec(pre[1]);
+            const float f = am_sigmoid_rec(pre[2]);
+            const float o = am_sigmoid_rec(pre[3]);
             const float ai = a * i;
             const float fc = f * cprev[e];
             const float c = ai + fc;
             const size_t cidx = (size_t)slot * U_pad + ut * 16 + eu;
             Ls.Cst[cidx] = c;
-            Ls.Hout[cidx] = o * tanhf(c);
+            Ls.Hout[cidx] = o * am_tanh_rec(c);
         }
     }
 }
@@ -1133,16 +1158,16 @@ __global__ __launch_bounds__(512) void lstm_thin_kernel(const LstmWavefrontArgs 
             }
             pre[k] = (ev + od) + gpre[k];
         }
-        const float a = tanhf(pre[0]);
-        const float i = am_sigmoid(pre[1]);
-        const float f = am_sigmoid(pre[2]);
-        const float o = am_sigmoid(pre[3]);
+        const float a = am_tanh_rec(pre[0]);
+        const float i = am_sigmoid_rec(pre[1]);
+        const float f = am_sigmoid_rec(pre[2]);
+        const float o = am_sigmoid_rec(pre[3]);
         const float ai = a * i;
         const float fc = f * cprev;
         const float cn = ai + fc;
         const size_t cidx = (size_t)eslot * U_pad + 4 * q + euu;
         Ls.Cst[cidx] = cn;
-        Ls.Hout[cidx] = o * tanhf(cn);
+        Ls.Hout[cidx] = o * am_tanh_rec(cn);
     }
 }
 
@@ -1254,6 +1279,13 @@ __device__ __forceinline__ void persist_phase(__amdgpu_buffer_rsrc_t src, unsign
     __syncthreads();   // every fragment read is done: the tiles may be rewritten (next product / gate exchange)
 }
 
+// diagnostic build of the timeline (AM_LSTM_STAMPS=1): the ut == 0 workgroup of every group stamps the 100 MHz counter at 7
+// points of every step into a buffer nothing else reads
+__device__ __forceinline__ void persist_stamp(const LstmPersistArgs& a, int gidx, int ut, int t, int k)
+{
+    if (a.stamps && ut == 0 && threadIdx.x == 0) a.stamps[((size_t)gidx * a.T + t) * 8 + k] = __builtin_amdgcn_s_memrealtime();
+}
+
 template <int NBU, int NBL, int NT>
 __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const LstmPersistLayer& Ly, int li, int gidx, int ut, int t, int n_act, int row0,
                                              const f32x4 (&wu)[NBU ? NBU : 1][LSTM_KS], const f32x4 (&wl)[NBL][LSTM_KS], const float (&bias4)[4],
@@ -1283,16 +1315,20 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
     f32x4 acc[NT];
 #pragma unroll
     for (int r = 0; r < NT; ++r) acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    persist_stamp(a, gidx, ut, t, 0);
     if (NBU) {   // upward product: needs step t of the layer below (which runs ahead: normally no wait at all)
         if (!persist_wait(a, a.L[li - 1].group0, a.L[li - 1].n_groups, t, s_flag)) return false;
+        persist_stamp(a, gidx, ut, t, 1);
         const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.Hin, 0, 0x7fffffff, 0x00020000);
         persist_phase<NBU ? NBU : 1, NT>(src, r_t, rows_valid, U_pad, wu, acc, sA0, sA1, tid, l15, lq, kh);
+        persist_stamp(a, gidx, ut, t, 2);
     }
     float cprev[EP];
 #pragma unroll
     for (int e = 0; e < EP; ++e) cprev[e] = 0.0f;
     if (t > 0) {  // lateral product: needs step t-1 of every group of this layer (the rows were cut differently then)
         if (!persist_wait(a, Ly.group0, Ly.n_groups, t - 1, s_flag)) return false;
+        persist_stamp(a, gidx, ut, t, 3);
 #pragma unroll
         for (int e = 0; e < EP; ++e) {
             const int idx = tid + 512 * e, erow = idx >> 4, eu = idx & 15;
@@ -1301,6 +1337,7 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
         }
         const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.H, 0, 0x7fffffff, 0x00020000);
         persist_phase<NBL, NT>(src, (unsigned)(a.step_off[t - 1] + row0), rows_valid, U_pad, wl, acc, sA0, sA1, tid, l15, lq, kh);
+        persist_stamp(a, gidx, ut, t, 4);
     }
     float* sg = smem;   // [kh][gate][ROWS][17], aliases the A tiles (both products end with a barrier)
 #pragma unroll
@@ -1317,21 +1354,23 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 pre[k] = (sg[((0 * 4 + k) * ROWS + erow) * 17 + eu] + sg[((1 * 4 + k) * ROWS + erow) * 17 + eu]) + gpre[e][k];
-            const float ga = tanhf(pre[0]);
-            const float gi = am_sigmoid(pre[1]);
-            const float gf = am_sigmoid(pre[2]);
-            const float go = am_sigmoid(pre[3]);
+            const float ga = am_tanh_rec(pre[0]);
+            const float gi = am_sigmoid_rec(pre[1]);
+            const float gf = am_sigmoid_rec(pre[2]);
+            const float go = am_sigmoid_rec(pre[3]);
             const float ai = ga * gi;
             const float fc = gf * cprev[e];
             const float c = ai + fc;
             __hip_atomic_store(Ly.Cst + (size_t)(row0 + erow) * U_pad + ut * 16 + eu, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(Ly.H + (size_t)(r_t + erow) * U_pad + ut * 16 + eu, go * tanhf(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(Ly.H + (size_t)(r_t + erow) * U_pad + ut * 16 + eu, go * am_tanh_rec(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    persist_stamp(a, gidx, ut, t, 5);
     // publish: every storing wave drains its stores, the workgroup meets, ONE lane signals for all of them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(a.counters + gidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    persist_stamp(a, gidx, ut, t, 6);
     return true;
 }
 
@@ -1409,16 +1448,10 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_kernel(const LstmPersistA
     else persist_body<0, NB, lstm_persist_ntmax(NB, false)>(a, Ly, li, gidx, ut, persist_smem, &s_flag);
 }
 
-static int lstm_persist_mode()
-{
-    static int mode = -1;   // AM_LSTM_PERSIST=0 keeps the per-step kernels (A/B measurements)
-    if (mode < 0) { const char* v = getenv("AM_LSTM_PERSIST"); mode = v ? atoi(v) : 1; }
-    return mode;
-}
+int lstm_persist_mode();
 
 bool plan_lstm_persist(LstmPersistArgs& a, int n_slots, const int* n_active, unsigned* cum_out)
 {
-    if (!lstm_persist_mode()) return false;
     if (a.n_layers < 1 || a.n_layers > LSTM_MAX_LAYERS || a.T <= 0 || n_slots <= 0) return false;
     if (a.U_pad != 256 && a.U_pad != 512) return false;
     const int nb = a.U_pad / LSTM_KB, tpg = a.U_pad / 16, budget = 256 / tpg;   // groups the chip can hold at one workgroup per CU
@@ -1468,6 +1501,388 @@ hipError_t launch_lstm_persist(hipStream_t s, const LstmPersistArgs& a)
     if (grid <= 0 || grid > 256) return hipErrorInvalidValue;
     if (a.U_pad == 512) hipLaunchKernelGGL(lstm_persist_kernel<4>, dim3(grid), dim3(512), LSTM_PERSIST_LDS, s, a);
     else if (a.U_pad == 256) hipLaunchKernelGGL(lstm_persist_kernel<2>, dim3(grid), dim3(512), LSTM_PERSIST_LDS, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Second persistent form: upward and lateral products in DIFFERENT workgroups.
+//
+// The timeline of the first form (tools/lstm_stamps.py, 3x512, 192 rows) shows a 23 us step for 13.7 us of MFMA time: the
+// two products run back to back in one workgroup (each pays its own pipeline start, ~2 us), then the gate math (1.8 us),
+// the publish (0.6 us) and the waits -- all serial, with the CU's matrix pipes idle meanwhile; and with few rows the
+// upward product sits on the recurrence's critical path although it does not depend on it.
+// Here a workgroup is 256 threads = 4 waves (wave = gate: 16 gate columns x the whole K = 512 in 128 VGPRs), two
+// workgroups per CU, and there are two kinds:
+//   upward  (layer l >= 1, row group g, unit tile): G_l[t] = h_{l-1}[t] . Wup^T + b   as soon as layer l-1 has produced h[t]
+//   lateral (layer l,      row group g, unit tile): pre = h_l[t-1] . Wlat^T + G_l[t]; gates, c, h[t]
+// Layer 0's G comes from the hoisted bulk GEMM as before; G_l of the upper layers travels through memory like h (sc1 stores /
+// sc1 loads / arrival counter: 16 KB per workgroup and step, off the critical path because the upward groups run ahead).
+// A CU's two workgroups are independent instruction streams on the same matrix pipes: while one waits, loads its first
+// tile or does gate math, the other multiplies.  The recurrence's chain per step shrinks to
+// [poll] [h tile] [lateral MFMAs] [gates] [publish].
+// Row groups are re-cut every step exactly as in the first form (q = ceil(tiles / groups); the upward and lateral groups
+// of a layer use the same cut, so lateral group g consumes what upward group g produced).
+// Summation order (this form's own; the posteriors of a frame are independent of batch composition and sharding, which
+// is what the tests pin): per gate column, MFMA steps with even j accumulate into one chain, odd j into another, both in
+// ascending k; pre = (even + odd) + G, G = (even + odd) + b.
+// ---------------------------------------------------------------------------------------------------
+constexpr int P2_KB = 64;                   // k per batch
+constexpr int P2_LDA = P2_KB + 8;           // LDS row stride of an A tile (floats): +32 B -> ds_read_b128 of (row l15, 16-B chunk lq) is conflict-free in every
+                                            // 16-lane service group (a stride of +16 B leaves a 2-way conflict per group: SQ_LDS_BANK_CONFLICT, profiles/r2b)
+constexpr int P2_ROWS = 64;                 // rows per workgroup and step (4 MFMA row tiles)
+constexpr int P2_SGLD = 20;                 // gate-exchange row stride (16 units + 16 B)
+constexpr size_t P2_LDS = 2 * P2_ROWS * P2_LDA * sizeof(float);   // 34,816 B; the gate exchange [4][64][20] aliases it
+
+__device__ __forceinline__ void st_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, 0, 16 /* sc1 */);
+}
+
+__device__ __forceinline__ void p2_stamp(const LstmP2Args& a, int gidx, int ut, int t, int k)
+{
+    if (a.stamps && ut == 0 && threadIdx.x == 0) a.stamps[((size_t)gidx * a.T + t) * 8 + k] = __builtin_amdgcn_s_memrealtime();
+}
+
+// lanes 0..n-1 of wave 0 poll counters first.. (step column tcol), lane n polls `extra` (column extra_tcol) if extra >= 0
+__device__ __forceinline__ bool p2_wait(const LstmP2Args& a, int first, int n, int tcol, int extra, int extra_tcol, int* s_flag)
+{
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int idx = -1, col = 0;
+        if (lane < n) { idx = first + lane; col = tcol; }
+        else if (lane == n && extra >= 0) { idx = extra; col = extra_tcol; }
+        bool ok = true;
+        if (idx >= 0) {
+            const unsigned target = a.cum[(size_t)idx * a.T + col];
+            const unsigned* c = a.counters + idx;
+            if (ld_agent_u32(c) < target) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                int it = 0;
+                while (ld_agent_u32(c) < target) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++it & 63) == 0 && (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                                            __builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)LSTM_P_TIMEOUT)) { ok = false; break; }
+                }
+            }
+        }
+        if (!ok) { __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *s_flag = 1; }
+    }
+    __syncthreads();
+    return *s_flag == 0;
+}
+
+// rows [row_base, row_base + 16 NT) of `src` (ld = U_pad; only the first rows_valid are loaded) times the resident fragments w
+// (this wave's 16 columns, all of K); `mid` runs once, two batches before the end (the step's epilogue operands are fetched there)
+template <int NBK, int NT, class Mid>
+__device__ __forceinline__ void p2_product(__amdgpu_buffer_rsrc_t src, unsigned row_base, int rows_valid, int U_pad, const f32x4 (&w)[NBK][4],
+                                           f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], float* sA0, float* sA1, int tid, int l15, int lq, Mid&& mid)
+{
+    f32x4 av[2][NT];
+    auto load_a = [&](int b, f32x4 (&dst)[NT]) {
+#pragma unroll
+        for (int e = 0; e < NT; ++e) {
+            const int c = tid + 256 * e, r = c >> 4, c4 = c & 15;
+            dst[e] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (r < rows_valid) dst[e] = ld_sc1_b128(src, ((row_base + r) * (unsigned)U_pad + (unsigned)(b * P2_KB + 4 * c4)) * 4u);
+        }
+    };
+    load_a(0, av[0]);
+    load_a(1, av[1]);
+#pragma unroll
+    for (int b = 0; b < NBK; ++b) {
+        float* sA = (b & 1) ? sA1 : sA0;
+#pragma unroll
+        for (int e = 0; e < NT; ++e) {
+            const int c = tid + 256 * e, r = c >> 4, c4 = c & 15;
+            *(f32x4*)(sA + r * P2_LDA + 4 * c4) = av[b & 1][e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // tile b is complete; everyone left tile b-2 (same buffer) before barrier b-1
+        if (b + 2 < NBK) load_a(b + 2, av[b & 1]);
+        if (b == NBK - 2) mid();
+        const float* sa = sA + l15 * P2_LDA + 4 * lq;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4 af[NT];
+#pragma unroll
+            for (int r = 0; r < NT; ++r) af[r] = *(const f32x4*)(sa + r * 16 * P2_LDA + 16 * s);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < NT; ++r) {
+                    if (j & 1) acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][j], w[b][s][j], acc1[r], 0, 0, 0);
+                    else acc0[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][j], w[b][s][j], acc0[r], 0, 0, 0);
+                }
+        }
+    }
+    __syncthreads();   // every fragment read is done: the tiles may be rewritten (gate exchange / next step)
+}
+
+template <int NT>
+__device__ __forceinline__ void p2_publish(const LstmP2Args& a, int gidx)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores,
+    __syncthreads();                                    // the workgroup meets,
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(a.counters + gidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ONE lane signals
+}
+
+// one step of a lateral workgroup
+template <int NBK, int NT>
+__device__ __forceinline__ bool p2_step_lat(const LstmP2Args& a, const LstmP2Group& G, const LstmP2Layer& Ly, int gidx, int ut, int t, int n_act, int row0,
+                                            const f32x4 (&w)[NBK][4], float* smem, int* s_flag)
+{
+    constexpr int ROWS = NT * 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int gate = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int U_pad = a.U_pad;
+    const int rows_valid = n_act - row0;                                       // > 0
+    const unsigned slot0 = (unsigned)(a.slot_base + row0);
+    const unsigned r_t = (unsigned)a.step_off[t] + slot0;                      // packed row of this group's first slot at step t
+    float* sA0 = smem;
+    float* sA1 = smem + P2_ROWS * P2_LDA;
+    p2_stamp(a, gidx, ut, t, 0);
+    if (t > 0 || G.g_src >= 0) {
+        if (!p2_wait(a, G.wait_first, t > 0 ? G.wait_n : 0, t > 0 ? t - 1 : 0, G.g_src, t, s_flag)) return false;
+    }
+    p2_stamp(a, gidx, ut, t, 1);
+    // epilogue operands of thread (row, unit quad): the four gates' upward terms and the previous cell state
+    const int erow = tid >> 2, quad = tid & 3;
+    const bool live = erow < ROWS && erow < rows_valid;
+    f32x4 gq[4], cq = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.G, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.Cst, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.H, 0, 0x7fffffff, 0x00020000);
+    auto fetch_epilogue = [&] {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            gq[k] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (live) gq[k] = ld_sc1_b128(grs, ((r_t + erow) * (unsigned)(4 * U_pad) + (unsigned)(ut * 64 + k * 16 + 4 * quad)) * 4u);
+        }
+        if (live && t > 0) cq = ld_sc1_b128(crs, ((slot0 + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u);
+    };
+    f32x4 acc0[NT], acc1[NT];
+#pragma unroll
+    for (int r = 0; r < NT; ++r) { acc0[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; acc1[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
+    if (t > 0) p2_product<NBK, NT>(hrs, (unsigned)a.step_off[t - 1] + slot0, rows_valid, U_pad, w, acc0, acc1, sA0, sA1, tid, l15, lq, fetch_epilogue);
+    else fetch_epilogue();
+    p2_stamp(a, gidx, ut, t, 2);
+    float* sg = smem;   // [gate][P2_ROWS][P2_SGLD]
+#pragma unroll
+    for (int r = 0; r < NT; ++r)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            sg[(gate * P2_ROWS + r * 16 + lq * 4 + reg) * P2_SGLD + l15] = acc0[r][reg] + acc1[r][reg];
+    __syncthreads();
+    p2_stamp(a, gidx, ut, t, 3);
+    if (live) {
+        f32x4 pre[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pre[k] = *(const f32x4*)(sg + (k * P2_ROWS + erow) * P2_SGLD + 4 * quad) + gq[k];
+        f32x4 cn, hn;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float ga = am_tanh_rec(pre[0][u]);
+            const float gi = am_sigmoid_rec(pre[1][u]);
+            const float gf = am_sigmoid_rec(pre[2][u]);
+            const float go = am_sigmoid_rec(pre[3][u]);
+            const float ai = ga * gi;
+            const float fc = gf * cq[u];
+            const float c = ai + fc;
+            cn[u] = c;
+            hn[u] = go * am_tanh_rec(c);
+        }
+        st_sc1_b128(crs, ((slot0 + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u, cn);
+        st_sc1_b128(hrs, ((r_t + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u, hn);
+    }
+    p2_stamp(a, gidx, ut, t, 5);
+    p2_publish<NT>(a, gidx);
+    p2_stamp(a, gidx, ut, t, 6);
+    return true;
+}
+
+// one step of an upward workgroup: G[t] rows of its group = h_below[t] . Wup^T + b
+template <int NBK, int NT>
+__device__ __forceinline__ bool p2_step_up(const LstmP2Args& a, const LstmP2Group& G, const LstmP2Layer& Ly, const LstmP2Layer& Lb, int gidx, int ut, int t, int n_act, int row0,
+                                           const f32x4 (&w)[NBK][4], float bias, float* smem, int* s_flag)
+{
+    constexpr int ROWS = NT * 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int gate = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int U_pad = a.U_pad;
+    const int rows_valid = n_act - row0;
+    const unsigned r_t = (unsigned)a.step_off[t] + (unsigned)(a.slot_base + row0);
+    float* sA0 = smem;
+    float* sA1 = smem + P2_ROWS * P2_LDA;
+    p2_stamp(a, gidx, ut, t, 0);
+    if (!p2_wait(a, G.wait_first, G.wait_n, t, -1, 0, s_flag)) return false;
+    p2_stamp(a, gidx, ut, t, 1);
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)Lb.H, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.G, 0, 0x7fffffff, 0x00020000);
+    f32x4 acc0[NT], acc1[NT];
+#pragma unroll
+    for (int r = 0; r < NT; ++r) { acc0[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; acc1[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
+    if (!a.debug_skip_upward) p2_product<NBK, NT>(hrs, r_t, rows_valid, U_pad, w, acc0, acc1, sA0, sA1, tid, l15, lq, [] {});
+    p2_stamp(a, gidx, ut, t, 2);
+    float* sg = smem;
+#pragma unroll
+    for (int r = 0; r < NT; ++r)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            sg[(gate * P2_ROWS + r * 16 + lq * 4 + reg) * P2_SGLD + l15] = (acc0[r][reg] + acc1[r][reg]) + bias;
+    __syncthreads();
+    p2_stamp(a, gidx, ut, t, 3);
+    const int erow = tid >> 2, quad = tid & 3;
+    if (erow < ROWS && erow < rows_valid) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            st_sc1_b128(grs, ((r_t + erow) * (unsigned)(4 * U_pad) + (unsigned)(ut * 64 + k * 16 + 4 * quad)) * 4u,
+                        *(const f32x4*)(sg + (k * P2_ROWS + erow) * P2_SGLD + 4 * quad));
+    }
+    p2_stamp(a, gidx, ut, t, 5);
+    p2_publish<NT>(a, gidx);
+    p2_stamp(a, gidx, ut, t, 6);
+    return true;
+}
+
+template <int NBK, int KIND>
+__device__ __forceinline__ void p2_body(const LstmP2Args& a, const LstmP2Group& G, int gidx, int ut, float* smem, int* s_flag)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int gate = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int U_pad = a.U_pad;
+    const LstmP2Layer& Ly = a.L[G.layer];
+    f32x4 w[NBK][4];   // the resident weights: this wave's 16 gate columns x all of K
+    {
+        const float* W = KIND ? Ly.Wup : Ly.Wlat;
+        const size_t wrow = (size_t)(ut * 64 + gate * 16 + l15) * U_pad + 4 * lq;
+#pragma unroll
+        for (int b = 0; b < NBK; ++b)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) w[b][s] = *(const f32x4*)(W + wrow + b * P2_KB + 16 * s);
+    }
+    const float bias = KIND ? Ly.bias[ut * 64 + gate * 16 + l15] : 0.0f;
+    for (int t = 0; t < a.T; ++t) {
+        int n_act = a.n_active[t] - a.slot_base;
+        if (n_act > a.slot_cap) n_act = a.slot_cap;
+        const int tiles = (n_act + 15) >> 4;
+        if (tiles <= 0) break;
+        const int q = (tiles + G.ng - 1) / G.ng;          // <= 4 (host plan)
+        const int tile0 = G.g * q;
+        int nt = tiles - tile0;
+        if (nt > q) nt = q;
+        if (nt <= 0) continue;
+        const int row0 = tile0 * 16;
+        bool ok = true;
+        if (KIND) {
+            const LstmP2Layer& Lb = a.L[G.layer - 1];
+            switch (nt) {
+            case 1: ok = p2_step_up<NBK, 1>(a, G, Ly, Lb, gidx, ut, t, n_act, row0, w, bias, smem, s_flag); break;
+            case 2: ok = p2_step_up<NBK, 2>(a, G, Ly, Lb, gidx, ut, t, n_act, row0, w, bias, smem, s_flag); break;
+            case 3: ok = p2_step_up<NBK, 3>(a, G, Ly, Lb, gidx, ut, t, n_act, row0, w, bias, smem, s_flag); break;
+            default: ok = p2_step_up<NBK, 4>(a, G, Ly, Lb, gidx, ut, t, n_act, row0, w, bias, smem, s_flag); break;
+            }
+        } else {
+            switch (nt) {
+            case 1: ok = p2_step_lat<NBK, 1>(a, G, Ly, gidx, ut, t, n_act, row0, w, smem, s_flag); break;
+            case 2: ok = p2_step_lat<NBK, 2>(a, G, Ly, gidx, ut, t, n_act, row0, w, smem, s_flag); break;
+            case 3: ok = p2_step_lat<NBK, 3>(a, G, Ly, gidx, ut, t, n_act, row0, w, smem, s_flag); break;
+            default: ok = p2_step_lat<NBK, 4>(a, G, Ly, gidx, ut, t, n_act, row0, w, smem, s_flag); break;
+            }
+        }
+        if (!ok) return;
+    }
+}
+
+__device__ __forceinline__ bool p2_prio() { return true; }
+
+template <int NBK>
+__global__ __launch_bounds__(256, 2) void lstm_persist2_kernel(const LstmP2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float p2_smem[];
+    __shared__ int s_flag;
+    if (threadIdx.x == 0) s_flag = 0;
+    __syncthreads();
+    // role: workgroups b and b + 8 are neighbours of one group, so under round-robin placement (b % 8 = XCD) a group's
+    // workgroups share an XCD and its L2 (speed only): group = (b % 8) + 8 * ((b / 8) / tiles), unit tile = (b / 8) % tiles
+    const int tpg = a.U_pad / 16;
+    const int j = blockIdx.x >> 3;
+    const int gidx = (blockIdx.x & 7) + 8 * (j / tpg), ut = j % tpg;
+    if (gidx >= a.n_groups) return;
+    const LstmP2Group& G = a.groups[gidx];
+    // the lateral workgroups are the recurrence's critical path: their waves win the issue arbitration against the upward
+    // workgroup that shares their SIMDs (static priority, MI355X_MICROARCH.md "two waves per SIMD" item 4)
+    if (G.kind) p2_body<NBK, 1>(a, G, gidx, ut, p2_smem, &s_flag);
+    else { if (p2_prio()) __builtin_amdgcn_s_setprio(3); p2_body<NBK, 0>(a, G, gidx, ut, p2_smem, &s_flag); }
+}
+
+int lstm_persist_mode()
+{
+    static int mode = -1;   // AM_LSTM_PERSIST: 0 per-step kernels, 1 first persistent form, 2 split upward / lateral form (default)
+    if (mode < 0) { const char* v = getenv("AM_LSTM_PERSIST"); mode = v ? atoi(v) : 2; }
+    return mode;
+}
+
+int lstm_persist2_capacity(int U_pad, int n_layers)
+{
+    if (U_pad != 256 && U_pad != 512) return 0;
+    const int groups_per_ng = 2 * n_layers - 1;          // lateral groups of every layer + upward groups of the upper layers
+    const int ng = P2_MAX_GROUPS / groups_per_ng;        // row groups per layer the 16 group slots allow
+    return ng * 64;                                      // 4 row tiles per group
+}
+
+bool plan_lstm_persist2(LstmP2Args& a, int n_slots, const int* n_active, unsigned* cum_out)
+{
+    if (a.n_layers < 1 || a.n_layers > LSTM_MAX_LAYERS || a.T <= 0 || n_slots <= 0) return false;
+    if (n_slots > lstm_persist2_capacity(a.U_pad, a.n_layers)) return false;
+    const int tpg = a.U_pad / 16;
+    const int tiles0 = (n_slots + 15) / 16;
+    const int kinds = 2 * a.n_layers - 1;
+    // as many row groups per layer as the chip holds (<= 16 groups, <= 512 workgroups): fewer tiles per group and step
+    int ng = (tiles0 + 3) / 4;
+    while ((ng + 1) * kinds <= P2_MAX_GROUPS && (ng + 1) * kinds * tpg <= 512 && ng < tiles0) ++ng;
+    int n = 0;
+    int lat0[LSTM_MAX_LAYERS], up0[LSTM_MAX_LAYERS];
+    for (int l = 0; l < a.n_layers; ++l) { lat0[l] = n; n += ng; }
+    for (int l = 1; l < a.n_layers; ++l) { up0[l] = n; n += ng; }
+    a.n_groups = n;
+    for (int l = 0; l < a.n_layers; ++l)
+        for (int g = 0; g < ng; ++g) {
+            LstmP2Group& G = a.groups[lat0[l] + g];
+            G.kind = 0; G.layer = l; G.g = g; G.ng = ng; G.wait_first = lat0[l]; G.wait_n = ng; G.g_src = l > 0 ? up0[l] + g : -1;
+        }
+    for (int l = 1; l < a.n_layers; ++l)
+        for (int g = 0; g < ng; ++g) {
+            LstmP2Group& G = a.groups[up0[l] + g];
+            G.kind = 1; G.layer = l; G.g = g; G.ng = ng; G.wait_first = lat0[l - 1]; G.wait_n = ng; G.g_src = -1;
+        }
+    if (cum_out) {
+        for (int gi = 0; gi < n; ++gi) {
+            const int g = a.groups[gi].g;
+            unsigned* row = cum_out + (size_t)gi * a.T;
+            unsigned c = 0;
+            for (int t = 0; t < a.T; ++t) {
+                int na = n_active[t] - a.slot_base;
+                if (na > a.slot_cap) na = a.slot_cap;
+                const int tiles = na > 0 ? (na + 15) / 16 : 0, q = (tiles + ng - 1) / ng;
+                if (tiles > 0 && g * q < tiles) c += (unsigned)tpg;
+                row[t] = c;
+            }
+        }
+    }
+    return true;
+}
+
+hipError_t launch_lstm_persist2(hipStream_t s, const LstmP2Args& a)
+{
+    const int tpg = a.U_pad / 16;
+    const int grid = 8 * tpg * ((a.n_groups + 7) / 8);
+    if (a.n_groups <= 0 || a.n_groups > P2_MAX_GROUPS || grid > 512) return hipErrorInvalidValue;
+    if (a.U_pad == 512) hipLaunchKernelGGL(lstm_persist2_kernel<8>, dim3(grid), dim3(256), P2_LDS, s, a);
+    else if (a.U_pad == 256) hipLaunchKernelGGL(lstm_persist2_kernel<4>, dim3(grid), dim3(256), P2_LDS, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -1636,25 +2051,25 @@ __device__ __forceinline__ void rec_epilogue(const float (&pre)[G], float e0, fl
 {
     if (EPI == REC_MGRU || EPI == REC_GRU_B) {
         // linear_interpolate(z, h~, h) = z*h~ + (1-z)*h ; without a previous state h = z*h~ (MGRU.py:77-84)
-        const float z = EPI == REC_MGRU ? am_sigmoid(pre[0]) : e1;
-        const float hb = am_activate(pre[G - 1], act);
+        const float z = EPI == REC_MGRU ? am_sigmoid_rec(pre[0]) : e1;
+        const float hb = am_activate_rec(pre[G - 1], act);
         float h = z * hb;
         if (!first) { const float keep = (1.0f - z) * e0; h = h + keep; }
         Ls.O0[eidx] = h;
     } else if (EPI == REC_GRU_A) {
-        Ls.O0[eidx] = am_sigmoid(pre[G - 1]);                                   // z
-        Ls.O1[eidx] = first ? 0.0f : am_sigmoid(pre[0]) * e0;                   // r * h_prev
+        Ls.O0[eidx] = am_sigmoid_rec(pre[G - 1]);                                   // z
+        Ls.O1[eidx] = first ? 0.0f : am_sigmoid_rec(pre[0]) * e0;                   // r * h_prev
     } else if (EPI == REC_PEEP_A) {
-        const float a = tanhf(pre[0]);
-        const float i = am_sigmoid(pre[1 % G]);
-        const float f = am_sigmoid(pre[2 % G]);
+        const float a = am_tanh_rec(pre[0]);
+        const float i = am_sigmoid_rec(pre[1 % G]);
+        const float f = am_sigmoid_rec(pre[2 % G]);
         const float ai = a * i;
         const float fc = f * e0;
         Ls.O0[eidx] = ai + fc;                                                  // c'
         Ls.O1[eidx] = pre[3 % G];                                               // o before its peephole term
     } else {                                                                    // REC_PEEP_B
-        const float o = am_sigmoid(e1 + pre[0]);
-        Ls.O0[eidx] = o * tanhf(e0);
+        const float o = am_sigmoid_rec(e1 + pre[0]);
+        Ls.O0[eidx] = o * am_tanh_rec(e0);
     }
 }
 
