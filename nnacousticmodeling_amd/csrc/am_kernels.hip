@@ -28,7 +28,8 @@ __device__ __forceinline__ float am_activate(float v, int act) {
 // Gate math of the recurrent cells.  libm's tanhf costs ~60 instructions; an LSTM step evaluates five of them per unit and
 // row, which was 2 of the 23 us of a 192-row step.  tanh(x) = 1 - 2 / (exp(2|x|) + 1) on the hardware exp2 / rcp for
 // |x| >= 0.25 and an odd polynomial below: max abs error 1.1e-7 over [-12, 12] (numpy's float32 tanh: 6e-8), ~1/6 of the
-// instructions.  sigmoid keeps Chainer's CPU form tanh(x/2)/2 + 1/2.  Every recurrent kernel uses these two, so a frame's
+// instructions.  sigmoid = 1 / (1 + exp(-x)) on the same two instructions (abs error 1.2e-7; Chainer's CPU form
+// tanh(x/2)/2 + 1/2 is the same function).  Every recurrent kernel uses these two, so a frame's
 // posteriors do not depend on the kernel form that computed them.
 __device__ __forceinline__ float am_tanh_rec(float x)
 {
@@ -43,7 +44,7 @@ __device__ __forceinline__ float am_tanh_rec(float x)
     const float poly = fmaf(ax, p, ax);
     return copysignf(ax < 0.25f ? poly : t, x);
 }
-__device__ __forceinline__ float am_sigmoid_rec(float x) { return am_tanh_rec(x * 0.5f) * 0.5f + 0.5f; }
+__device__ __forceinline__ float am_sigmoid_rec(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }   // 1 / (1 + exp(-x))
 __device__ __forceinline__ float am_activate_rec(float v, int act) {
     if (act == 0) return fmaxf(v, 0.0f);
     if (act == 1) return am_sigmoid_rec(v);
@@ -752,7 +753,8 @@ hipError_t launch_splice_tdnn(hipStream_t s, const SpliceArgs& a, int W, int Cp,
 constexpr int LSTM_RB = 64;               // rows per block
 constexpr int LSTM_KB = 128;              // k per batch (both K halves)
 constexpr int LSTM_KS = LSTM_KB / 32;     // 16-k sub-steps per wave per batch
-constexpr int LSTM_LDA = LSTM_KB + 4;     // LDS row stride (floats): +16 B -> conflict-free ds_read_b128
+constexpr int LSTM_LDA = LSTM_KB + 8;     // LDS row stride (floats): +32 B -> ds_read_b128 of (row l15, chunk lq) is conflict-free in every 16-lane service
+                                          // group (+16 B left a 2-way conflict per group: SQ_LDS_BANK_CONFLICT, profiles/r2b)
 constexpr int LSTM_APT = LSTM_RB * LSTM_KB / 4 / 512;  // 16-B A chunks per thread per batch
 
 template <int NT>
@@ -1206,6 +1208,11 @@ __device__ __forceinline__ f32x4 ld_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned 
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16 /* sc1 */));
 }
 
+__device__ __forceinline__ void st_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, 0, 16 /* sc1 */);
+}
+
 // Wave 0, lane j < n polls counter first + j until it reaches cum[(first + j) * T + tcol]; then the workgroup's barrier.
 // Returns false (all threads) when the pass has been aborted.
 __device__ __forceinline__ bool persist_wait(const LstmPersistArgs& a, int first, int n, int tcol, int* s_flag)
@@ -1231,68 +1238,107 @@ __device__ __forceinline__ bool persist_wait(const LstmPersistArgs& a, int first
     return *s_flag == 0;
 }
 
-// NB batches of 128 k of one product: A rows [row_base, row_base + 16 NT) of `src` (only the first rows_valid are loaded)
-// times the resident weight fragments w; tiles staged through the double-buffered LDS tile as in lstm_wreg_body.
-template <int NB, int NT>
-__device__ __forceinline__ void persist_phase(__amdgpu_buffer_rsrc_t src, unsigned row_base, int rows_valid, int U_pad, const f32x4 (&w)[NB][LSTM_KS],
-                                              f32x4 (&acc)[NT], float* sA0, float* sA1, int tid, int l15, int lq, int kh)
+// The products of one step as ONE pipeline of 128-k batches: NBU batches of the upward product (rows of `up` at row_up),
+// then -- if LAT -- NBL batches of the lateral product (rows of `lat` at row_lat).  Tiles travel global -> registers (two
+// batches ahead) -> double-buffered LDS tile -> MFMA fragments, as in lstm_wreg_body, but the weights never move.
+// `lat_wait` runs once, just before the first lateral tile is requested (the upward batches in flight cover it);
+// `mid` runs once, two batches before the end (the epilogue's operands are requested there).  Only the first rows_valid
+// rows are loaded.  Summation order: the per-step kernels' (64-k chains from zero, folded per K half in batch order).
+template <int NBU, int NBL, bool LAT, int NT, class Wait, class Mid>
+__device__ __forceinline__ bool persist_products(__amdgpu_buffer_rsrc_t up, unsigned row_up, __amdgpu_buffer_rsrc_t lat, unsigned row_lat, int rows_valid, int U_pad,
+                                                 const f32x4 (&wu)[NBU ? NBU : 1][LSTM_KS], const f32x4 (&wl)[NBL][LSTM_KS], f32x4 (&acc)[NT],
+                                                 float* sA0, float* sA1, int tid, int l15, int lq, int kh, Wait&& lat_wait, Mid&& mid)
 {
-    f32x4 av[2][NT];
+    constexpr int NBT = NBU + (LAT ? NBL : 0);
+    // tiles in flight in registers: two batches ahead with <= 2 row tiles; one with more, where the registers go to the double-
+    // buffered MFMA fragments instead (a batch's MFMAs, >= 1.3 us, still cover the load)
+    constexpr int D = NT >= 3 ? 1 : 2;
+    bool ok = true;
+    f32x4 av[D][NT];
     auto load_a = [&](int b, f32x4 (&dst)[NT]) {
+        const bool is_up = b < NBU;
+        const __amdgpu_buffer_rsrc_t src = is_up ? up : lat;
+        const unsigned rb = is_up ? row_up : row_lat;
+        const int kb = is_up ? b : b - NBU;
 #pragma unroll
         for (int e = 0; e < NT; ++e) {
             const int idx = tid + 512 * e, r = idx >> 5, c4 = idx & 31;
             dst[e] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            if (r < rows_valid) dst[e] = ld_sc1_b128(src, ((row_base + r) * (unsigned)U_pad + (unsigned)(b * LSTM_KB + 4 * c4)) * 4u);
+            if (r < rows_valid) dst[e] = ld_sc1_b128(src, ((rb + r) * (unsigned)U_pad + (unsigned)(kb * LSTM_KB + 4 * c4)) * 4u);
         }
     };
-    load_a(0, av[0]);
-    if (NB > 1) load_a(1, av[1]);
+    if (LAT && NBU < D) ok = lat_wait();          // a lateral tile is among the first requests
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
+    for (int b = 0; b < D; ++b) if (b < NBT) load_a(b, av[b]);
+#pragma unroll
+    for (int b = 0; b < NBT; ++b) {
         float* sA = (b & 1) ? sA1 : sA0;
 #pragma unroll
         for (int e = 0; e < NT; ++e) {
             const int idx = tid + 512 * e, r = idx >> 5, c4 = idx & 31;
-            *(f32x4*)(sA + r * LSTM_LDA + 4 * c4) = av[b & 1][e];
+            *(f32x4*)(sA + r * LSTM_LDA + 4 * c4) = av[b % D][e];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // tile b is complete; everyone left tile b-2 (same buffer) before barrier b-1
-        if (b + 2 < NB) load_a(b + 2, av[b & 1]);
+        if (LAT && NBU >= D && b + D == NBU) ok = lat_wait() && ok;
+        if (b + D < NBT) load_a(b + D, av[b % D]);
+        if (b + 2 == NBT || (NBT == 1 && b == 0)) mid();
         const float* sa = sA + l15 * LSTM_LDA + kh * (LSTM_KB / 2) + 4 * lq;
         f32x4 pb[NT];
 #pragma unroll
         for (int r = 0; r < NT; ++r) pb[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        if (NT <= 2) {   // few rows: the step is latency-bound, fetch the whole batch's fragments before the first MFMA
+            f32x4 af[LSTM_KS][NT];
 #pragma unroll
-        for (int s = 0; s < LSTM_KS; ++s) {
-            f32x4 af[NT];
+            for (int s = 0; s < LSTM_KS; ++s)
 #pragma unroll
-            for (int r = 0; r < NT; ++r) af[r] = *(const f32x4*)(sa + r * 16 * LSTM_LDA + 16 * s);
+                for (int r = 0; r < NT; ++r) af[s][r] = *(const f32x4*)(sa + r * 16 * LSTM_LDA + 16 * s);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int s = 0; s < LSTM_KS; ++s)
 #pragma unroll
-                for (int r = 0; r < NT; ++r) pb[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][j], w[b][s][j], pb[r], 0, 0, 0);
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < NT; ++r)
+                        pb[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s][r][j], (b < NBU ? wu[b < NBU ? b : 0][s][j] : wl[b < NBU ? 0 : b - NBU][s][j]), pb[r], 0, 0, 0);
+        } else {         // the fragments of sub-step s + 1 are requested before the MFMAs of sub-step s (the LDS latency was exposed 4x per batch)
+            f32x4 af[2][NT];
+#pragma unroll
+            for (int r = 0; r < NT; ++r) af[0][r] = *(const f32x4*)(sa + r * 16 * LSTM_LDA);
+#pragma unroll
+            for (int s = 0; s < LSTM_KS; ++s) {
+                if (s + 1 < LSTM_KS) {
+#pragma unroll
+                    for (int r = 0; r < NT; ++r) af[(s + 1) & 1][r] = *(const f32x4*)(sa + r * 16 * LSTM_LDA + 16 * (s + 1));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < NT; ++r)
+                        pb[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s & 1][r][j], (b < NBU ? wu[b < NBU ? b : 0][s][j] : wl[b < NBU ? 0 : b - NBU][s][j]), pb[r], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int r = 0; r < NT; ++r) acc[r] += pb[r];
     }
-    __syncthreads();   // every fragment read is done: the tiles may be rewritten (next product / gate exchange)
+    if (NBT > 0) __syncthreads();   // every fragment read is done: the tiles may be rewritten (gate exchange)
+    return ok;
 }
 
-// diagnostic build of the timeline (AM_LSTM_STAMPS=1): the ut == 0 workgroup of every group stamps the 100 MHz counter at 7
+// diagnostic build of the timeline (AM_LSTM_STAMPS=1): the ut == 0 workgroup of every group stamps the 100 MHz counter at
 // points of every step into a buffer nothing else reads
 __device__ __forceinline__ void persist_stamp(const LstmPersistArgs& a, int gidx, int ut, int t, int k)
 {
     if (a.stamps && ut == 0 && threadIdx.x == 0) a.stamps[((size_t)gidx * a.T + t) * 8 + k] = __builtin_amdgcn_s_memrealtime();
 }
 
+constexpr int PERSIST_SGLD = 20;   // gate-exchange row stride: 16 units + 16 B (f32x4 reads stay aligned, b32 writes conflict-free)
+
 template <int NBU, int NBL, int NT>
 __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const LstmPersistLayer& Ly, int li, int gidx, int ut, int t, int n_act, int row0,
-                                             const f32x4 (&wu)[NBU ? NBU : 1][LSTM_KS], const f32x4 (&wl)[NBL][LSTM_KS], const float (&bias4)[4],
+                                             const f32x4 (&wu)[NBU ? NBU : 1][LSTM_KS], const f32x4 (&wl)[NBL][LSTM_KS],
                                              float* smem, int tile_rows, int* s_flag)
 {
     constexpr int ROWS = NT * 16;
-    constexpr int EP = (ROWS * 16 + 511) / 512;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int gate = wave & 3, kh = wave >> 2;
@@ -1302,68 +1348,79 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
     const unsigned r_t = (unsigned)(a.step_off[t] + row0);      // packed row of slot row0 at step t
     float* sA0 = smem;
     float* sA1 = smem + tile_rows * LSTM_LDA;
-
-    float gpre[EP][4];
-#pragma unroll
-    for (int e = 0; e < EP; ++e) {
-        const int idx = tid + 512 * e, erow = idx >> 4, eu = idx & 15;
-        const bool live = erow < ROWS && erow < rows_valid;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            gpre[e][k] = NBU ? bias4[k] : (live ? Ly.G[(size_t)(r_t + erow) * ldg + ut * 64 + k * 16 + eu] : 0.0f);
-    }
-    f32x4 acc[NT];
-#pragma unroll
-    for (int r = 0; r < NT; ++r) acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     persist_stamp(a, gidx, ut, t, 0);
     if (NBU) {   // upward product: needs step t of the layer below (which runs ahead: normally no wait at all)
         if (!persist_wait(a, a.L[li - 1].group0, a.L[li - 1].n_groups, t, s_flag)) return false;
-        persist_stamp(a, gidx, ut, t, 1);
-        const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.Hin, 0, 0x7fffffff, 0x00020000);
-        persist_phase<NBU ? NBU : 1, NT>(src, r_t, rows_valid, U_pad, wu, acc, sA0, sA1, tid, l15, lq, kh);
+    }
+    persist_stamp(a, gidx, ut, t, 1);
+    // epilogue of thread (row, unit quad): the four gates' upward terms (G rows of layer 0, the bias otherwise), previous cell state
+    const int erow = tid >> 2, quad = tid & 3;
+    const bool live = erow < ROWS && erow < rows_valid;
+    f32x4 gq[4], cq = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.Cst, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.H, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void*)(NBU ? Ly.Hin : Ly.H), 0, 0x7fffffff, 0x00020000);
+    // layer 0 (64 VGPRs of weights) requests its G rows two batches before the end of the product; the upper layers (128 VGPRs
+    // of weights, no register to spare during the products) fetch their bias -- cache-resident -- behind the gate exchange
+    auto fetch_g = [&] {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            gq[k] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (live) gq[k] = NBU ? *(const f32x4*)(Ly.bias + ut * 64 + k * 16 + 4 * quad)
+                                  : *(const f32x4*)(Ly.G + (size_t)(r_t + erow) * ldg + ut * 64 + k * 16 + 4 * quad);
+        }
+    };
+    auto fetch_epilogue = [&] {
+        if (!NBU) fetch_g();
+        if (live && t > 0) cq = ld_sc1_b128(crs, ((unsigned)(row0 + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u);
+    };
+    auto lat_wait = [&] { return persist_wait(a, Ly.group0, Ly.n_groups, t - 1, s_flag); };   // step t-1 of every group of this layer
+    f32x4 acc[NT];
+#pragma unroll
+    for (int r = 0; r < NT; ++r) acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    bool ok = true;
+    // layer 0: one pipeline (lateral only).  Upper layers: two pipelines -- a single one over both products keeps both weight sets,
+    // the tiles in flight and the wait's state live at once and spills 40-60 VGPRs into the MFMA loop (measured: 36 us per step
+    // against 23); the upward product's MFMAs still run in the shadow of the other workgroups' step t-1
+    if (NBU) {
+        const bool last = t == 0;
+        if (last) ok = persist_products<NBU, NBL, false, NT>(urs, r_t, hrs, 0u, rows_valid, U_pad, wu, wl, acc, sA0, sA1, tid, l15, lq, kh, lat_wait, fetch_epilogue);
+        else ok = persist_products<NBU, NBL, false, NT>(urs, r_t, hrs, 0u, rows_valid, U_pad, wu, wl, acc, sA0, sA1, tid, l15, lq, kh, lat_wait, [] {});
         persist_stamp(a, gidx, ut, t, 2);
     }
-    float cprev[EP];
-#pragma unroll
-    for (int e = 0; e < EP; ++e) cprev[e] = 0.0f;
-    if (t > 0) {  // lateral product: needs step t-1 of every group of this layer (the rows were cut differently then)
-        if (!persist_wait(a, Ly.group0, Ly.n_groups, t - 1, s_flag)) return false;
-        persist_stamp(a, gidx, ut, t, 3);
-#pragma unroll
-        for (int e = 0; e < EP; ++e) {
-            const int idx = tid + 512 * e, erow = idx >> 4, eu = idx & 15;
-            if (erow < ROWS && erow < rows_valid)
-                cprev[e] = __hip_atomic_load(Ly.Cst + (size_t)(row0 + erow) * U_pad + ut * 16 + eu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.H, 0, 0x7fffffff, 0x00020000);
-        persist_phase<NBL, NT>(src, (unsigned)(a.step_off[t - 1] + row0), rows_valid, U_pad, wl, acc, sA0, sA1, tid, l15, lq, kh);
-        persist_stamp(a, gidx, ut, t, 4);
-    }
-    float* sg = smem;   // [kh][gate][ROWS][17], aliases the A tiles (both products end with a barrier)
+    f32x4 wnone[1][LSTM_KS] = {};   // stands in for the absent upward weights of a lateral-only pipeline (never read)
+    if (t > 0) ok = persist_products<0, NBL, true, NT>(hrs, 0u, hrs, (unsigned)(a.step_off[t - 1] + row0), rows_valid, U_pad, wnone, wl, acc, sA0, sA1, tid, l15, lq, kh, lat_wait, fetch_epilogue) && ok;
+    else if (!NBU) fetch_epilogue();
+    if (!ok) return false;
+    persist_stamp(a, gidx, ut, t, 4);
+    float* sg = smem;   // [kh][gate][ROWS][PERSIST_SGLD], aliases the A tiles (the products end with a barrier)
 #pragma unroll
     for (int r = 0; r < NT; ++r)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
-            sg[((kh * 4 + gate) * ROWS + r * 16 + lq * 4 + reg) * 17 + l15] = acc[r][reg];
+            sg[((kh * 4 + gate) * ROWS + r * 16 + lq * 4 + reg) * PERSIST_SGLD + l15] = acc[r][reg];
+    if (NBU) fetch_g();
     __syncthreads();
+    if (live) {
+        f32x4 pre[4];
 #pragma unroll
-    for (int e = 0; e < EP; ++e) {
-        const int idx = tid + 512 * e, erow = idx >> 4, eu = idx & 15;
-        if (erow < ROWS && erow < rows_valid) {
-            float pre[4];
+        for (int k = 0; k < 4; ++k)
+            pre[k] = (*(const f32x4*)(sg + ((0 * 4 + k) * ROWS + erow) * PERSIST_SGLD + 4 * quad) + *(const f32x4*)(sg + ((1 * 4 + k) * ROWS + erow) * PERSIST_SGLD + 4 * quad)) + gq[k];
+        f32x4 cn, hn;
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                pre[k] = (sg[((0 * 4 + k) * ROWS + erow) * 17 + eu] + sg[((1 * 4 + k) * ROWS + erow) * 17 + eu]) + gpre[e][k];
-            const float ga = am_tanh_rec(pre[0]);
-            const float gi = am_sigmoid_rec(pre[1]);
-            const float gf = am_sigmoid_rec(pre[2]);
-            const float go = am_sigmoid_rec(pre[3]);
+        for (int u = 0; u < 4; ++u) {
+            const float ga = am_tanh_rec(pre[0][u]);
+            const float gi = am_sigmoid_rec(pre[1][u]);
+            const float gf = am_sigmoid_rec(pre[2][u]);
+            const float go = am_sigmoid_rec(pre[3][u]);
             const float ai = ga * gi;
-            const float fc = gf * cprev[e];
+            const float fc = gf * cq[u];
             const float c = ai + fc;
-            __hip_atomic_store(Ly.Cst + (size_t)(row0 + erow) * U_pad + ut * 16 + eu, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(Ly.H + (size_t)(r_t + erow) * U_pad + ut * 16 + eu, go * am_tanh_rec(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cn[u] = c;
+            hn[u] = go * am_tanh_rec(c);
         }
+        st_sc1_b128(crs, ((unsigned)(row0 + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u, cn);
+        st_sc1_b128(hrs, ((r_t + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u, hn);
     }
     persist_stamp(a, gidx, ut, t, 5);
     // publish: every storing wave drains its stores, the workgroup meets, ONE lane signals for all of them
@@ -1398,11 +1455,6 @@ __device__ __forceinline__ void persist_body(const LstmPersistArgs& a, const Lst
                 for (int s = 0; s < LSTM_KS; ++s) wu[b][s] = *(const f32x4*)(Ly.Wup + wrow + b * LSTM_KB + 16 * s);
         }
     }
-    float bias4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (NBU) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) bias4[k] = Ly.bias[ut * 64 + k * 16 + (tid & 15)];
-    }
     for (int t = 0; t < a.T; ++t) {
         const int n_act = a.n_active[t];
         const int tiles = (n_act + 15) >> 4;
@@ -1415,12 +1467,12 @@ __device__ __forceinline__ void persist_body(const LstmPersistArgs& a, const Lst
         bool ok = true;
         const int row0 = tile0 * 16;
         switch (nt) {
-        case 1: ok = persist_step<NBU, NBL, 1>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, bias4, smem, NTMAX * 16, s_flag); break;
-        case 2: ok = persist_step<NBU, NBL, 2>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, bias4, smem, NTMAX * 16, s_flag); break;
-        case 3: ok = persist_step<NBU, NBL, 3>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, bias4, smem, NTMAX * 16, s_flag); break;
-        case 4: ok = persist_step<NBU, NBL, 4>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, bias4, smem, NTMAX * 16, s_flag); break;
-        case 5: if (NTMAX >= 5) ok = persist_step<NBU, NBL, NTMAX >= 5 ? 5 : 1>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, bias4, smem, NTMAX * 16, s_flag); break;
-        case 6: if (NTMAX >= 6) ok = persist_step<NBU, NBL, NTMAX >= 6 ? 6 : 1>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, bias4, smem, NTMAX * 16, s_flag); break;
+        case 1: ok = persist_step<NBU, NBL, 1>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, smem, NTMAX * 16, s_flag); break;
+        case 2: ok = persist_step<NBU, NBL, 2>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, smem, NTMAX * 16, s_flag); break;
+        case 3: ok = persist_step<NBU, NBL, 3>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, smem, NTMAX * 16, s_flag); break;
+        case 4: ok = persist_step<NBU, NBL, 4>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, smem, NTMAX * 16, s_flag); break;
+        case 5: if (NTMAX >= 5) ok = persist_step<NBU, NBL, NTMAX >= 5 ? 5 : 1>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, smem, NTMAX * 16, s_flag); break;
+        case 6: if (NTMAX >= 6) ok = persist_step<NBU, NBL, NTMAX >= 6 ? 6 : 1>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, smem, NTMAX * 16, s_flag); break;
         default: break;
         }
         if (!ok) return;
@@ -1534,10 +1586,6 @@ constexpr int P2_ROWS = 64;                 // rows per workgroup and step (4 MF
 constexpr int P2_SGLD = 20;                 // gate-exchange row stride (16 units + 16 B)
 constexpr size_t P2_LDS = 2 * P2_ROWS * P2_LDA * sizeof(float);   // 34,816 B; the gate exchange [4][64][20] aliases it
 
-__device__ __forceinline__ void st_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v)
-{
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, 0, 16 /* sc1 */);
-}
 
 __device__ __forceinline__ void p2_stamp(const LstmP2Args& a, int gidx, int ut, int t, int k)
 {
