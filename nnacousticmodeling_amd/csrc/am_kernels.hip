@@ -1238,52 +1238,88 @@ __device__ __forceinline__ bool persist_wait(const LstmPersistArgs& a, int first
     return *s_flag == 0;
 }
 
-// The products of one step as ONE pipeline of 128-k batches: NBU batches of the upward product (rows of `up` at row_up),
-// then -- if LAT -- NBL batches of the lateral product (rows of `lat` at row_lat).  Tiles travel global -> registers (two
-// batches ahead) -> double-buffered LDS tile -> MFMA fragments, as in lstm_wreg_body, but the weights never move.
-// `lat_wait` runs once, just before the first lateral tile is requested (the upward batches in flight cover it);
-// `mid` runs once, two batches before the end (the epilogue's operands are requested there).  Only the first rows_valid
-// rows are loaded.  Summation order: the per-step kernels' (64-k chains from zero, folded per K half in batch order).
+// A pipeline of 128-k batches of one step's products: NBU batches of the upward product (rows of `up` at row_up), then -- if
+// LAT -- NBL batches of the lateral product (rows of `lat` at row_lat), against the resident weight fragments.
+// Tiles travel global -> LDS by LDS-DMA (global_load_lds_dwordx4, sc1: no VGPR staging, so up to three further tiles are in
+// flight while one is multiplied -- the timeline showed 9.7 us per 4-batch product for 6.85 us of MFMA time with one or two
+// tiles in flight in registers: the step is bound by the latency of the hand-off loads, not by the matrix pipe).
+// LDS image of a tile: [rows][128 floats], unpadded (a DMA instruction writes 64 x 16 B contiguously = two rows); the 16-B
+// chunk index is XOR-ed with the row's low four bits ON THE SOURCE ADDRESS, so the ds_read_b128 of (row l15, chunk 4s + lq) is
+// conflict-free in every 16-lane service group.  Ring of NBUF tile buffers; tile i + NBUF - 1 is requested right after the
+// barrier that ends tile i - 1.  Only the first rows_valid rows are read: rows beyond alias rows of step t + 1 that another XCD
+// may not have written yet (a line fetched early would stay stale in this XCD's L2); their tile rows repeat the last valid row
+// and feed only output rows nobody stores.  `lat_wait` runs once, before the first lateral tile is requested; `mid` once, two
+// batches before the end (the epilogue's operands are requested there).
+// Summation order: the per-step kernels' (64-k chains from zero, folded per K half in batch order).
+__device__ __forceinline__ void wait_vmcnt(int k)
+{
+    switch (k) {   // folds to one instruction: k is a constant after unrolling
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+constexpr int PERSIST_TILE_LD = LSTM_KB;                              // floats per tile row (no padding: swizzled)
+constexpr size_t PERSIST_RING_BYTES = 3 * 96 * PERSIST_TILE_LD * sizeof(float);   // 147,456 B: 3 x 96 rows or 4 x 64 rows
+
 template <int NBU, int NBL, bool LAT, int NT, class Wait, class Mid>
-__device__ __forceinline__ bool persist_products(__amdgpu_buffer_rsrc_t up, unsigned row_up, __amdgpu_buffer_rsrc_t lat, unsigned row_lat, int rows_valid, int U_pad,
+__device__ __forceinline__ bool persist_products(const float* up, unsigned row_up, const float* lat, unsigned row_lat, int rows_valid, int U_pad,
                                                  const f32x4 (&wu)[NBU ? NBU : 1][LSTM_KS], const f32x4 (&wl)[NBL][LSTM_KS], f32x4 (&acc)[NT],
-                                                 float* sA0, float* sA1, int tid, int l15, int lq, int kh, Wait&& lat_wait, Mid&& mid)
+                                                 float* ring, int tid, int l15, int lq, int kh, Wait&& lat_wait, Mid&& mid)
 {
     constexpr int NBT = NBU + (LAT ? NBL : 0);
-    // tiles in flight in registers: two batches ahead with <= 2 row tiles; one with more, where the registers go to the double-
-    // buffered MFMA fragments instead (a batch's MFMAs, >= 1.3 us, still cover the load)
-    constexpr int D = NT >= 3 ? 1 : 2;
+    constexpr int BUF_ROWS = NT <= 4 ? 64 : 96;
+    constexpr int NBUF = NT <= 4 ? 4 : 3;
+    constexpr int BUF_FLOATS = BUF_ROWS * PERSIST_TILE_LD;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     bool ok = true;
-    f32x4 av[D][NT];
-    auto load_a = [&](int b, f32x4 (&dst)[NT]) {
+    // DMA instruction e of this wave covers tile rows 2 (wave + 8 e) and + 1: lane -> (row, stored chunk); source chunk = stored ^ (row & 15)
+    const int drow = lane >> 5, dchunk = lane & 31;
+    auto issue = [&](int b) {
         const bool is_up = b < NBU;
-        const __amdgpu_buffer_rsrc_t src = is_up ? up : lat;
+        const float* src = is_up ? up : lat;
         const unsigned rb = is_up ? row_up : row_lat;
         const int kb = is_up ? b : b - NBU;
+        float* buf = ring + (b % NBUF) * BUF_FLOATS;
 #pragma unroll
         for (int e = 0; e < NT; ++e) {
-            const int idx = tid + 512 * e, r = idx >> 5, c4 = idx & 31;
-            dst[e] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            if (r < rows_valid) dst[e] = ld_sc1_b128(src, ((rb + r) * (unsigned)U_pad + (unsigned)(kb * LSTM_KB + 4 * c4)) * 4u);
+            const int wi = wave + 8 * e, row = 2 * wi + drow;
+            const int c = dchunk ^ (row & 15);
+            // rows past the valid ones re-read the last valid row (never a row that may not have been written yet); no lane is
+            // masked, so every wave issues exactly NT DMA instructions per tile -- the counted vmcnt waits below rely on that
+            const int srow = row < rows_valid ? row : rows_valid - 1;
+            __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(src + (size_t)(rb + srow) * U_pad + kb * LSTM_KB + 4 * c), AM_LDS_PTR(buf + wi * 256), 16, 0, 16 /* sc1 */);
         }
     };
-    if (LAT && NBU < D) ok = lat_wait();          // a lateral tile is among the first requests
+    if (LAT && NBU < NBUF - 1 && NBU < NBT) ok = lat_wait();          // a lateral tile is among the first requests
 #pragma unroll
-    for (int b = 0; b < D; ++b) if (b < NBT) load_a(b, av[b]);
+    for (int b = 0; b < NBUF - 1; ++b) if (b < NBT) issue(b);
+    // fragment addressing: row r*16 + l15, chunk (kh*16 + 4 s + lq) ^ l15
+    const float* fbase = ring + l15 * PERSIST_TILE_LD + kh * (LSTM_KB / 2);
+    int xs[LSTM_KS];
+#pragma unroll
+    for (int s = 0; s < LSTM_KS; ++s) xs[s] = 4 * (((4 * s + lq) ^ l15) & 15);
 #pragma unroll
     for (int b = 0; b < NBT; ++b) {
-        float* sA = (b & 1) ? sA1 : sA0;
-#pragma unroll
-        for (int e = 0; e < NT; ++e) {
-            const int idx = tid + 512 * e, r = idx >> 5, c4 = idx & 31;
-            *(f32x4*)(sA + r * LSTM_LDA + 4 * c4) = av[b % D][e];
+        const int issued = (b + NBUF - 1 < NBT) ? b + NBUF - 1 : NBT;     // tiles requested so far
+        wait_vmcnt(NT * (issued - (b + 1)));                               // tile b has landed (this wave's part)
+        __builtin_amdgcn_s_barrier();                                      // ... everybody's; and everyone has left tile b-1
+        if (b + NBUF - 1 < NBT) {
+            if (LAT && NBU >= NBUF - 1 && b + NBUF - 1 == NBU) ok = lat_wait() && ok;
+            issue(b + NBUF - 1);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // tile b is complete; everyone left tile b-2 (same buffer) before barrier b-1
-        if (LAT && NBU >= D && b + D == NBU) ok = lat_wait() && ok;
-        if (b + D < NBT) load_a(b + D, av[b % D]);
         if (b + 2 == NBT || (NBT == 1 && b == 0)) mid();
-        const float* sa = sA + l15 * LSTM_LDA + kh * (LSTM_KB / 2) + 4 * lq;
+        const float* sa = fbase + (b % NBUF) * BUF_FLOATS;
         f32x4 pb[NT];
 #pragma unroll
         for (int r = 0; r < NT; ++r) pb[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
@@ -1292,7 +1328,7 @@ __device__ __forceinline__ bool persist_products(__amdgpu_buffer_rsrc_t up, unsi
 #pragma unroll
             for (int s = 0; s < LSTM_KS; ++s)
 #pragma unroll
-                for (int r = 0; r < NT; ++r) af[s][r] = *(const f32x4*)(sa + r * 16 * LSTM_LDA + 16 * s);
+                for (int r = 0; r < NT; ++r) af[s][r] = *(const f32x4*)(sa + r * 16 * PERSIST_TILE_LD + xs[s]);
 #pragma unroll
             for (int s = 0; s < LSTM_KS; ++s)
 #pragma unroll
@@ -1300,15 +1336,15 @@ __device__ __forceinline__ bool persist_products(__amdgpu_buffer_rsrc_t up, unsi
 #pragma unroll
                     for (int r = 0; r < NT; ++r)
                         pb[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s][r][j], (b < NBU ? wu[b < NBU ? b : 0][s][j] : wl[b < NBU ? 0 : b - NBU][s][j]), pb[r], 0, 0, 0);
-        } else {         // the fragments of sub-step s + 1 are requested before the MFMAs of sub-step s (the LDS latency was exposed 4x per batch)
+        } else {         // the fragments of sub-step s + 1 are requested before the MFMAs of sub-step s
             f32x4 af[2][NT];
 #pragma unroll
-            for (int r = 0; r < NT; ++r) af[0][r] = *(const f32x4*)(sa + r * 16 * LSTM_LDA);
+            for (int r = 0; r < NT; ++r) af[0][r] = *(const f32x4*)(sa + r * 16 * PERSIST_TILE_LD + xs[0]);
 #pragma unroll
             for (int s = 0; s < LSTM_KS; ++s) {
                 if (s + 1 < LSTM_KS) {
 #pragma unroll
-                    for (int r = 0; r < NT; ++r) af[(s + 1) & 1][r] = *(const f32x4*)(sa + r * 16 * LSTM_LDA + 16 * (s + 1));
+                    for (int r = 0; r < NT; ++r) af[(s + 1) & 1][r] = *(const f32x4*)(sa + r * 16 * PERSIST_TILE_LD + xs[s + 1 < LSTM_KS ? s + 1 : 0]);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -1320,7 +1356,7 @@ __device__ __forceinline__ bool persist_products(__amdgpu_buffer_rsrc_t up, unsi
 #pragma unroll
         for (int r = 0; r < NT; ++r) acc[r] += pb[r];
     }
-    if (NBT > 0) __syncthreads();   // every fragment read is done: the tiles may be rewritten (gate exchange)
+    if (NBT > 0) __syncthreads();   // every fragment read is done: the ring may be rewritten (gate exchange, next pipeline)
     return ok;
 }
 
@@ -1346,8 +1382,6 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
     const int U_pad = a.U_pad, ldg = 4 * U_pad;
     const int rows_valid = n_act - row0;                       // > 0
     const unsigned r_t = (unsigned)(a.step_off[t] + row0);      // packed row of slot row0 at step t
-    float* sA0 = smem;
-    float* sA1 = smem + tile_rows * LSTM_LDA;
     persist_stamp(a, gidx, ut, t, 0);
     if (NBU) {   // upward product: needs step t of the layer below (which runs ahead: normally no wait at all)
         if (!persist_wait(a, a.L[li - 1].group0, a.L[li - 1].n_groups, t, s_flag)) return false;
@@ -1359,7 +1393,6 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
     f32x4 gq[4], cq = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.Cst, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.H, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc((void*)(NBU ? Ly.Hin : Ly.H), 0, 0x7fffffff, 0x00020000);
     // layer 0 (64 VGPRs of weights) requests its G rows two batches before the end of the product; the upper layers (128 VGPRs
     // of weights, no register to spare during the products) fetch their bias -- cache-resident -- behind the gate exchange
     auto fetch_g = [&] {
@@ -1384,12 +1417,12 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
     // against 23); the upward product's MFMAs still run in the shadow of the other workgroups' step t-1
     if (NBU) {
         const bool last = t == 0;
-        if (last) ok = persist_products<NBU, NBL, false, NT>(urs, r_t, hrs, 0u, rows_valid, U_pad, wu, wl, acc, sA0, sA1, tid, l15, lq, kh, lat_wait, fetch_epilogue);
-        else ok = persist_products<NBU, NBL, false, NT>(urs, r_t, hrs, 0u, rows_valid, U_pad, wu, wl, acc, sA0, sA1, tid, l15, lq, kh, lat_wait, [] {});
+        if (last) ok = persist_products<NBU, NBL, false, NT>(Ly.Hin, r_t, Ly.H, 0u, rows_valid, U_pad, wu, wl, acc, smem, tid, l15, lq, kh, lat_wait, fetch_epilogue);
+        else ok = persist_products<NBU, NBL, false, NT>(Ly.Hin, r_t, Ly.H, 0u, rows_valid, U_pad, wu, wl, acc, smem, tid, l15, lq, kh, lat_wait, [] {});
         persist_stamp(a, gidx, ut, t, 2);
     }
     f32x4 wnone[1][LSTM_KS] = {};   // stands in for the absent upward weights of a lateral-only pipeline (never read)
-    if (t > 0) ok = persist_products<0, NBL, true, NT>(hrs, 0u, hrs, (unsigned)(a.step_off[t - 1] + row0), rows_valid, U_pad, wnone, wl, acc, sA0, sA1, tid, l15, lq, kh, lat_wait, fetch_epilogue) && ok;
+    if (t > 0) ok = persist_products<0, NBL, true, NT>(Ly.H, 0u, Ly.H, (unsigned)(a.step_off[t - 1] + row0), rows_valid, U_pad, wnone, wl, acc, smem, tid, l15, lq, kh, lat_wait, fetch_epilogue) && ok;
     else if (!NBU) fetch_epilogue();
     if (!ok) return false;
     persist_stamp(a, gidx, ut, t, 4);
@@ -1480,7 +1513,7 @@ __device__ __forceinline__ void persist_body(const LstmPersistArgs& a, const Lst
 }
 
 constexpr int lstm_persist_ntmax(int nb, bool upward) { return (upward ? 2 * nb : nb) >= 8 ? 4 : 6; }   // by the register budget: K/8 VGPRs of weights
-constexpr size_t LSTM_PERSIST_LDS = 2 * 96 * LSTM_LDA * sizeof(float);   // two 96-row tiles; the gate exchange aliases them
+constexpr size_t LSTM_PERSIST_LDS = PERSIST_RING_BYTES;   // the tile ring; the gate exchange aliases it
 
 template <int NB>
 __global__ __launch_bounds__(512, 2) void lstm_persist_kernel(const LstmPersistArgs a)
