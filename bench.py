@@ -40,7 +40,8 @@ def parse_args():
     ap.add_argument("--model", default="4x1024", choices=sorted(FLOPS_PER_FRAME))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="skip the secondary split-f16 precision measurement")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline sample")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary records (end to end, N=57,919, 6x2048+ivec, 3x512 LSTM)")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="time budget of the CPU baseline samples (all of them together)")
     return ap.parse_args()
 
 
@@ -77,30 +78,186 @@ def pmc_traffic(kernel_prefix="am::gemm_nt_f32_kernel"):
     return (tot / n if n else None), os.path.relpath(files[-1], ROOT)
 
 
-def cpu_baseline(ft, params, layers, x, iv, seconds):
-    """The oracle (numpy restatement of the Chainer CPU forward, kind = "port") on a bounded sample of the same file:
-    predict()'s own batching -- 1024-frame batches: prepareBatch -> transform -> MLP -> y - logsum(y)."""
-    from oracle import am_oracle as orc
+def _blas_threads():
     try:
         from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        return max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
-        threads = os.cpu_count() or 1
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(ft, params, layers, x, iv, seconds):
+    """The oracle (numpy restatement of the Chainer CPU forward, kind = "port") on bounded samples of the same file.
+    Main figure: predict()'s own batching -- 1024-frame batches: prepareBatch -> transform -> MLP -> y - logsum(y), all BLAS
+    threads.  Beside it: the same with ONE BLAS thread, evaluate's per-utterance batching
+    (evaluateModelForTest.py:98-107: one forward per utterance, ~300 rows), and the reference's Python-loop splice
+    (kw_utils.py:24-36) on a 3,000-frame sample, which is where a real run of the reference spends its front-end time."""
+    from oracle import am_oracle as orc
     model = orc.MLP(params, layers)
-    done, t0 = 0, time.perf_counter()
-    while done < x.shape[0] and time.perf_counter() - t0 < seconds:
-        hi = min(done + 1024, x.shape[0])
-        xb = orc.prepare_batch(x, np.arange(done, hi), 11)
-        xb = orc.apply_feature_transform(xb, ft)
-        if iv is not None:
-            xb = np.concatenate((xb, iv[done:hi]), axis=1)
-        y = model(xb)
+
+    def predict_batches(budget):
+        done, t0 = 0, time.perf_counter()
+        while done < x.shape[0] and time.perf_counter() - t0 < budget:
+            hi = min(done + 1024, x.shape[0])
+            xb = orc.prepare_batch(x, np.arange(done, hi), 11)
+            xb = orc.apply_feature_transform(xb, ft)
+            if iv is not None:
+                xb = np.concatenate((xb, iv[done:hi]), axis=1)
+            y = model(xb)
+            y = y - orc.logsum(y, axis=1)
+            done = hi
+        return done, time.perf_counter() - t0
+
+    threads = int(_blas_threads())
+    done, dt = predict_batches(seconds * 0.5)
+    out = {"value": done / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": "first %d frames of the same synthetic file, 1024-frame batches as predict_folds.py:71-90 "
+                     "(numpy/BLAS restatement of the Chainer CPU forward; Chainer itself is not installable here), %.1f s" % (done, dt)}
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            d1, t1 = predict_batches(seconds * 0.2)
+        out["one_thread"] = {"value": d1 / t1, "unit": "frames/s", "cores": 1, "sample": "first %d frames, same batching, %.1f s" % (d1, t1)}
+    except Exception as exc:   # threadpoolctl missing: report, do not fail the bench
+        out["one_thread"] = {"value": None, "note": "threadpoolctl unavailable: %s" % exc}
+    # evaluate's batching: one forward per utterance on the already spliced + transformed file
+    rng = np.random.default_rng(SEED)
+    n_e = min(x.shape[0], 30000)
+    from nnacousticmodeling_amd.synthetic import make_offsets
+    off = make_offsets(rng, max(n_e // 300, 1), n_e)
+    data = orc.evaluate_frontend(x[:n_e], 5, ft, None if iv is None else iv[:n_e])
+    t0, u = time.perf_counter(), 0
+    while u < len(off) - 1 and time.perf_counter() - t0 < seconds * 0.2:
+        y = model(data[off[u]:off[u + 1]])
         y = y - orc.logsum(y, axis=1)
-        done = hi
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "frames/s", "cores": int(threads), "kind": "port",
-            "sample": "first %d frames of the same synthetic file, 1024-frame batches as predict_folds.py:71-90 "
-                      "(numpy/BLAS restatement of the Chainer CPU forward; Chainer itself is not installable here), %.1f s" % (done, dt)}
+        u += 1
+    te = time.perf_counter() - t0
+    out["per_utterance_batches"] = {"value": float(off[u] / te), "unit": "frames/s", "cores": threads,
+                                    "sample": "%d utterances (%d frames), one forward per utterance as evaluateModelForTest.py:98-107, "
+                                              "front end excluded, %.1f s" % (u, off[u], te)}
+    ns = min(3000, x.shape[0])
+    t0 = time.perf_counter()
+    orc.splice_rowloop(x[:ns], ft["shifts"])
+    ts = time.perf_counter() - t0
+    out["python_loop_splice"] = {"value": ns / ts, "unit": "frames/s", "cores": 1,
+                                 "sample": "the reference's per-row Python loop (kw_utils.py:24-36) on %d frames, %.3f s" % (ns, ts)}
+    return out
+
+
+def timed_runs(eng, fn, steps, warmup, barrier=None):
+    """(wall seconds of `steps` un-instrumented runs, {kernel: (launches, ms)} of `steps` further runs bracketed by HIP events).
+    The headline figure and the per-kernel profile come from SEPARATE loops: event bracketing perturbs what it measures."""
+    for _ in range(warmup):
+        fn()
+    eng.synchronize()
+    if barrier:
+        barrier()
+    eng.synchronize()
+    t0 = time.perf_counter()
+    eng.record(0)
+    for _ in range(steps):
+        fn()
+    eng.record(1)
+    eng.synchronize()
+    wall = time.perf_counter() - t0
+    if barrier:
+        barrier()
+    dev_ms = eng.elapsed_ms(0, 1)
+    eng.profile(True)
+    eng.profile_reset()
+    for _ in range(steps):
+        fn()
+    eng.synchronize()
+    prof = eng.profile_read()
+    eng.profile(False)
+    return wall, dev_ms, prof
+
+
+def gemm_roofline(prof, flops_total):
+    calls = sum(prof[k][0] for k in ("gemm_hidden", "gemm_out") if k in prof)
+    ms = sum(prof[k][1] for k in ("gemm_hidden", "gemm_out") if k in prof)
+    achieved = flops_total / (ms * 1e-3) / 1e12 if ms > 0 else None
+    return calls, ms, achieved
+
+
+def secondary_records(eng, ft, params, layers, x, steps):
+    """The other BASELINE.json configurations and SURVEY.md 8d figures, one GPU, outside the headline `value`:
+    end to end (host array in, pinned host array out), the core-test-like size, 6x2048 + i-vectors, the 3x512 LSTM."""
+    from nnacousticmodeling_amd.engine import Model, Pipeline
+    from nnacousticmodeling_amd.kaldi_ft import loadKaldiFeatureTransform, select_centre_frame
+    from nnacousticmodeling_amd.synthetic import make_lstm_params, make_mlp_params, make_offsets
+    out = {}
+    golden = os.path.join(ROOT, "tests", "golden")
+    n_full = x.shape[0]
+    m4 = Model(eng, "ff", layers, params)
+    # (i) end to end: H2D of the frames, compute, D2H of the posteriors into page-locked memory (PCIe-inclusive; never `value`)
+    p = Pipeline(eng)
+    p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+    p.set_members([m4])
+    y = eng.pinned_empty((n_full, 1909))
+    p.forward_ff(x, out=y)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        p.forward_ff(x, out=y)
+    dt = (time.perf_counter() - t0) / reps
+    out["end_to_end"] = {"value": n_full / dt, "unit": "frames/s", "ms_per_pass": dt * 1e3, "frames": n_full,
+                         "what": "host array -> H2D -> splice+transform+4x1024+log-softmax -> D2H into page-locked host memory "
+                                 "(7.6 KB of posteriors per frame over PCIe; download of chunk c overlaps compute of chunk c+1)"}
+    del y
+    # (ii) the same network at the TIMIT core-test size (57,919 frames = 226.2 row tiles: partial last round of tiles)
+    n57 = 57919
+    p.ff_upload(x[:n57], None, n57, 0, 0)
+    wall, _, prof = timed_runs(eng, p.ff_run, max(steps, 5), 2)
+    k = max(steps, 5)
+    _, _, ach = gemm_roofline(prof, FLOPS_PER_FRAME["4x1024"] * n57 * k)
+    out["n57919"] = {"value": n57 * k / wall, "unit": "frames/s", "ms_per_step": wall * 1e3 / k, "frames": n57,
+                     "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS if ach else None},
+                     "frac_of_mfma_ceiling_whole_step": FLOPS_PER_FRAME["4x1024"] * n57 * k / wall / 1e12 / PEAK_F32_MFMA_TFLOPS}
+    p.close()
+    m4.close()
+    # (iii) BASELINE configs[2]: 6x2048 on 440 spliced + 100 i-vector columns
+    rng = np.random.default_rng(SEED + 2)
+    p6 = make_mlp_params(rng, 540, 2048, 6, 1909)
+    iv = rng.standard_normal((n_full, 100)).astype(np.float32)
+    m6 = Model(eng, "ff", 6, p6)
+    p = Pipeline(eng)
+    p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"], 100)
+    p.set_members([m6])
+    p.ff_upload(x, iv, n_full, 0, 0)
+    k6 = max(steps // 4, 3)
+    wall, _, prof = timed_runs(eng, p.ff_run, k6, 1)
+    _, _, ach = gemm_roofline(prof, FLOPS_PER_FRAME["6x2048"] * n_full * k6)
+    out["dnn_6x2048_ivec"] = {"value": n_full * k6 / wall, "unit": "frames/s", "ms_per_step": wall * 1e3 / k6, "frames": n_full,
+                              "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS if ach else None}}
+    p.close()
+    m6.close()
+    del iv
+    # (iv) BASELINE configs[3]: 3x512 LSTM (uni-directional: the reference has no bidirectional net, SURVEY.md M1), 192 utterances
+    ftc = select_centre_frame(loadKaldiFeatureTransform(os.path.join(golden, "final.feature_transform")))
+    rng = np.random.default_rng(SEED + 3)
+    off = make_offsets(rng, 192, n57)
+    ml = Model(eng, "lstm", 3, make_lstm_params(rng, 40, 512, 3, 1909))
+    p = Pipeline(eng)
+    p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
+    p.set_members([ml])
+    p.lstm_upload(x[:n57], None, off, 0)
+    kl = max(steps // 2, 5)
+    wall, _, prof = timed_runs(eng, p.lstm_run, kl, 3)
+    fl = 2 * (40 * 2048 + 2 * 512 * 2048 + 3 * 512 * 2048 + 512 * 1909)
+    rec_ms = prof.get("lstm_step", (0, 0.0))[1] / kl
+    rec_flops = 2 * (2 * 512 * 2048 + 3 * 512 * 2048) * n57       # the recurrent kernel's share: lateral x3 + upward x2
+    out["lstm_3x512"] = {"value": n57 * kl / wall, "unit": "frames/s", "ms_per_pass": wall * 1e3 / kl, "frames": n57, "utterances": 192,
+                         "longest_utterance": int(np.diff(off).max()),
+                         "roofline": {"bound": "mfma (dependent time steps: latency-bound below ~64 active utterances)", "kernel": "whole pass",
+                                      "achieved": fl * n57 * kl / wall / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": fl * n57 * kl / wall / 1e12 / PEAK_F32_MFMA_TFLOPS},
+                         "recurrent_kernel": {"ms_per_pass": rec_ms, "launches_per_pass": prof.get("lstm_step", (0, 0.0))[0] // kl,
+                                              "achieved_tflops": rec_flops / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else None},
+                         "kernels_ms_per_pass": {k_: v[1] / kl for k_, v in prof.items()}}
+    p.close()
+    ml.close()
+    return out
 
 
 def main():
@@ -118,28 +275,9 @@ def main():
     pipe.set_members([Model(eng, "ff", layers, params)])
     pipe.ff_upload(x, iv, args.frames, 0, 0)  # inputs resident in HBM before the timed region
 
-    for _ in range(args.warmup):
-        pipe.ff_run()
-    eng.synchronize()
-
-    barrier = ranks.barrier
-
-    eng.profile(True)
-    eng.profile_reset()
-    barrier()
-    eng.synchronize()
-    t0 = time.perf_counter()
-    eng.record(0)
-    for _ in range(args.steps):
-        pipe.ff_run()
-    eng.record(1)
-    eng.synchronize()
-    t1 = time.perf_counter()
-    barrier()
-    wall = t1 - t0
-    dev_ms = eng.elapsed_ms(0, 1)
-    prof = eng.profile_read()
-    eng.profile(False)
+    # headline loop (no per-kernel events), then the same K steps again with every launch bracketed by HIP events on the
+    # engine's compute stream for the roofline figures
+    wall, dev_ms, prof = timed_runs(eng, pipe.ff_run, args.steps, args.warmup, ranks.barrier)
     wall = ranks.max_over_ranks(wall)
 
     # secondary measurement, outside the timed region and not part of `value`: the same pass with the Linear layers in the
@@ -148,19 +286,8 @@ def main():
     if not args.no_split:
         y_exact = pipe.ff_download()
         eng.set_precision("split_f16")
-        for _ in range(max(args.warmup, 1)):
-            pipe.ff_run()
-        eng.synchronize()
-        eng.profile(True)
-        eng.profile_reset()
-        barrier()
-        ts0 = time.perf_counter()
-        for _ in range(args.steps):
-            pipe.ff_run()
-        eng.synchronize()
-        wall_s = ranks.max_over_ranks(time.perf_counter() - ts0)
-        prof_s = eng.profile_read()
-        eng.profile(False)
+        wall_s, _, prof_s = timed_runs(eng, pipe.ff_run, args.steps, max(args.warmup, 1), ranks.barrier)
+        wall_s = ranks.max_over_ranks(wall_s)
         overflow = pipe.overflowed()
         y_split = pipe.ff_download()
         eng.set_precision("f32")
@@ -175,13 +302,15 @@ def main():
                                  "frac": f16 / 2500.0, "note": "operand stream (LDS-DMA, 64 flop/B at 256x256 tiles) is the practical bound: ~5.2 TB/s of ~6.4 TB/s"}
         del y_exact, y_split
 
+    secondary = None
+    if n_gpus == 1 and not args.no_secondary and args.model == "4x1024":
+        secondary = secondary_records(eng, ft, params, layers, x, args.steps)
+
     if rank == 0:
         frames_total = args.frames * args.steps * n_gpus
         value = frames_total / wall
-        gemm_calls = sum(prof[k][0] for k in ("gemm_hidden", "gemm_out") if k in prof)
-        gemm_ms = sum(prof[k][1] for k in ("gemm_hidden", "gemm_out") if k in prof)
         flops_step = FLOPS_PER_FRAME[args.model] * args.frames
-        achieved = flops_step * args.steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
+        gemm_calls, gemm_ms, achieved = gemm_roofline(prof, flops_step * args.steps)
         traffic, traffic_src = pmc_traffic() if (args.model == "4x1024" and args.frames == 196608) else (None, None)
         out = {
             "metric": "frames/sec (posterior compute), %s ReLU DNN, fbank40 splice+-5, fp32" % args.model,
@@ -197,11 +326,14 @@ def main():
                          "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC, %s)" % traffic_src if traffic else None,
                          "algorithmic_bytes_per_launch": (args.frames * 4 * (440 + 4 * 1024 + 4 * 1024 + 1909) + 4 * (440 * 1024 + 3 * 1024 * 1024 + 1024 * 1909)) / 5.0 if args.model == "4x1024" else None,
-                         "avg_launch_ms": gemm_ms / gemm_calls if gemm_calls else None},
+                         "avg_launch_ms": gemm_ms / gemm_calls if gemm_calls else None,
+                         "measured": "HIP events around every launch on the engine's compute stream, in a second loop of the same K steps (the headline loop carries no events)"},
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
         }
         if split is not None:
             out["split_f16"] = split
+        if secondary is not None:
+            out.update(secondary)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ft, params, layers, x, iv, args.cpu_seconds)
         print(json.dumps(out))

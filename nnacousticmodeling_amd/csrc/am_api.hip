@@ -151,11 +151,9 @@ struct am_pipeline {
     int timedelay = 0;
     // persistent form of the LSTM stack (lstm_persist_kernel): per member the group plan + arrival table, shared step tables
     struct PersistPlan {
-        int form = 0;                       // 0 per-step kernels, 1 lstm_persist_kernel, 2 lstm_persist2_kernel
-        LstmPersistArgs args{}; DevBuf cum; // form 1
-        std::vector<LstmP2Args> chunks;     // form 2: one launch per chunk of utterance slots
-        std::vector<DevBuf> cums;
-        void release() { cum.release(); for (auto& c : cums) c.release(); cums.clear(); chunks.clear(); form = 0; }
+        int form = 0;                       // 0 per-step kernels, 1 lstm_persist_kernel
+        LstmPersistArgs args{}; DevBuf cum;
+        void release() { cum.release(); form = 0; }
     };
     std::vector<PersistPlan> persist;
     DevBuf d_nact, d_stepoff, d_sync;   // int [T], int [T + 1], unsigned [groups + 1] (arrival counters, abort flag last)
@@ -1302,7 +1300,6 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
         HIP_TRY(hipMemcpyAsync(p->d_stepoff.p, soff.data(), sizeof(int) * soff.size(), hipMemcpyHostToDevice, e->stream));
         AM_TRY(p->d_sync.ensure(sizeof(unsigned) * 64));
         std::vector<std::vector<unsigned>> staging;   // alive until the copies below have been synchronised
-        int g_planes = 1;
         for (size_t mi = 0; mi < p->members.size(); ++mi) {
             am_model* m = p->members[mi];
             if (m->cell != AM_CELL_LSTM) continue;
@@ -1311,24 +1308,6 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
             if (!fits) continue;
             auto& pl = p->persist[mi];
             const int U_pad = m->L[0].U_pad;
-            const int cap = pmode >= 2 ? lstm_persist2_capacity(U_pad, m->n_layers) : 0;
-            if (cap > 0) {
-                // split form: chunks of `cap` utterance slots, one launch each (utterances are independent)
-                bool ok = true;
-                for (int base = 0; base < n_utts && ok; base += cap) {
-                    LstmP2Args a2{};
-                    a2.n_layers = m->n_layers; a2.U_pad = U_pad; a2.T = (int)T; a2.slot_base = base; a2.slot_cap = std::min(cap, n_utts - base);
-                    if (!plan_lstm_persist2(a2, a2.slot_cap, nact.data(), nullptr)) { ok = false; break; }
-                    staging.emplace_back((size_t)a2.n_groups * T);
-                    plan_lstm_persist2(a2, a2.slot_cap, nact.data(), staging.back().data());
-                    pl.cums.emplace_back();
-                    AM_TRY(pl.cums.back().ensure(sizeof(unsigned) * staging.back().size()));
-                    HIP_TRY(hipMemcpyAsync(pl.cums.back().p, staging.back().data(), sizeof(unsigned) * staging.back().size(), hipMemcpyHostToDevice, e->stream));
-                    pl.chunks.push_back(a2);
-                }
-                if (ok) { pl.form = 2; g_planes = std::max(g_planes, m->n_layers); continue; }
-                pl.release();
-            }
             pl.args = LstmPersistArgs{};
             pl.args.n_layers = m->n_layers; pl.args.U_pad = U_pad; pl.args.T = (int)T;
             if (!plan_lstm_persist(pl.args, n_utts, nact.data(), nullptr)) continue;
@@ -1338,7 +1317,6 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
             HIP_TRY(hipMemcpyAsync(pl.cum.p, staging.back().data(), sizeof(unsigned) * staging.back().size(), hipMemcpyHostToDevice, e->stream));
             pl.form = 1;
         }
-        if (g_planes > 1) AM_TRY(p->d_G.ensure(sizeof(float) * rows_alloc * gw * g_planes));   // one G plane per layer (split form)
         AM_TRY(sync_all(e));   // the staging vectors go out of scope here
     }
     AM_TRY(sync_all(e));
@@ -1499,35 +1477,7 @@ static int lstm_enqueue(am_pipeline* p)
         }
         float* Hall = p->d_H.as<float>();
         float* Call = p->d_c.as<float>();
-        if (p->persist[mi].form == 2) {
-            // split persistent form (lstm_persist2_kernel): one launch per chunk of utterance slots
-            static const bool want_stamps = env_int("AM_LSTM_STAMPS", 0) != 0;
-            const size_t g_stride = (size_t)(rows_pad + GEMM_BM) * m->L[0].out_pad;
-            for (size_t ci = 0; ci < p->persist[mi].chunks.size(); ++ci) {
-                LstmP2Args pa = p->persist[mi].chunks[ci];
-                for (int l = 0; l < NL; ++l) {
-                    Layer& Ly = m->L[l];
-                    LstmP2Layer& s = pa.L[l];
-                    s.G = p->d_G.as<float>() + l * g_stride;
-                    s.bias = Ly.b.as<float>(); s.Wup = l == 0 ? nullptr : Ly.W.as<float>(); s.Wlat = Ly.Wlat.as<float>();
-                    s.H = Hall + l * h_stride; s.Cst = Call + l * c_stride;
-                }
-                pa.n_active = p->d_nact.as<int>(); pa.step_off = p->d_stepoff.as<int>(); pa.cum = p->persist[mi].cums[ci].as<unsigned>();
-                pa.counters = p->d_sync.as<unsigned>(); pa.abort_flag = p->d_sync.as<int>() + 63;
-                static const bool skip_u = env_int("AM_P2_SKIP_U", 0) != 0;
-                pa.debug_skip_upward = skip_u ? 1 : 0;
-                if (want_stamps && ci == 0) {
-                    const size_t bytes = sizeof(unsigned long long) * 8 * (size_t)pa.n_groups * pa.T;
-                    AM_TRY(p->d_stamps.ensure(bytes));
-                    HIP_TRY(hipMemsetAsync(p->d_stamps.p, 0, bytes, e->stream));
-                    pa.stamps = p->d_stamps.as<unsigned long long>();
-                    p->stamps_groups = pa.n_groups; p->stamps_T = pa.T;
-                }
-                HIP_TRY(hipMemsetAsync(p->d_sync.p, 0, sizeof(unsigned) * 63, e->stream));
-                AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_persist2(e->stream, pa); }));
-            }
-            p->used_persist = true;
-        } else if (p->persist[mi].form == 1) {
+        if (p->persist[mi].form == 1) {
             // the whole stack and time axis in one persistent launch (lstm_persist_kernel)
             LstmPersistArgs pa = p->persist[mi].args;
             for (int l = 0; l < NL; ++l) {

@@ -147,43 +147,7 @@ bool plan_lstm_persist(LstmPersistArgs& a, int n_slots, const int* n_active_host
 size_t lstm_persist_cum_size(const LstmPersistArgs& a);   // entries of `cum`
 hipError_t launch_lstm_persist(hipStream_t s, const LstmPersistArgs& a);
 
-// Second persistent form (lstm_persist2_kernel): the upward and the lateral product of a layer run in DIFFERENT workgroups
-// (256 threads, two per CU), so the upward products leave the recurrence's critical path and one workgroup's waits, gate
-// math and publishing are covered by the other's MFMAs.  See the kernel's header.
-constexpr int P2_MAX_GROUPS = 16;
-struct LstmP2Layer {
-    float* G;            // [NP, 4*U_pad] time-major packed pre-activations of the upward term (+bias): layer 0's come from the
-                         // hoisted GEMM, the others are written by the layer's upward workgroups during the launch
-    const float* bias;   // layers >= 1: [4*U_pad] gate-tiled
-    const float* Wup;    // layers >= 1: [4*U_pad, U_pad] gate-tiled rows
-    const float* Wlat;   // [4*U_pad, U_pad] gate-tiled rows
-    float* H;            // packed H plane [>= NP, U_pad]
-    float* Cst;          // cell state [slots, U_pad]
-};
-struct LstmP2Group {
-    int kind;            // 0 lateral (gates, c, h), 1 upward (G)
-    int layer;
-    int g, ng;           // this group's index among the ng row groups of its (kind, layer)
-    int wait_first, wait_n;   // lateral: the lateral groups of its own layer (their step t-1); upward: the lateral groups of the layer below (their step t)
-    int g_src;           // lateral, layer >= 1: counter of the upward group whose rows it consumes (step t); else -1
-};
-struct LstmP2Args {
-    LstmP2Layer L[LSTM_MAX_LAYERS];
-    LstmP2Group groups[P2_MAX_GROUPS];
-    int n_layers, U_pad, T, n_groups;
-    int slot_base, slot_cap;       // this launch covers utterance slots [slot_base, slot_base + slot_cap)
-    int debug_skip_upward;         // timing experiments only (AM_P2_SKIP_U=1): the upward workgroups skip their product
-    const int* n_active;           // device [T]
-    const int* step_off;           // device [T + 1]
-    const unsigned* cum;           // device [n_groups][T]
-    unsigned* counters;            // device [n_groups], zero before the launch
-    int* abort_flag;
-    unsigned long long* stamps;    // diagnostic timeline [n_groups][T][8] or nullptr
-};
-bool plan_lstm_persist2(LstmP2Args& a, int n_slots, const int* n_active_host, unsigned* cum_out /*nullable*/);
-hipError_t launch_lstm_persist2(hipStream_t s, const LstmP2Args& a);
-int lstm_persist_mode();   // AM_LSTM_PERSIST: 0 per-step kernels, 1 first persistent form, 2 (default) split upward / lateral form
-int lstm_persist2_capacity(int U_pad, int n_layers);   // utterance slots one launch can take
+int lstm_persist_mode();   // AM_LSTM_PERSIST: 0 per-step kernels, 1 (default) the persistent form
 
 // Recurrent cells other than L.LSTM (GRU / MGRU / peephole LSTM): one phase of one wavefront tick, see rec_step_kernel.
 enum RecEpilogue {

@@ -1283,23 +1283,26 @@ __device__ __forceinline__ bool persist_products(const float* up, unsigned row_u
     constexpr int BUF_FLOATS = BUF_ROWS * PERSIST_TILE_LD;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     bool ok = true;
-    // DMA instruction e of this wave covers tile rows 2 (wave + 8 e) and + 1: lane -> (row, stored chunk); source chunk = stored ^ (row & 15)
+    // DMA instruction e of this wave covers tile rows 2 (wave + 8 e) and + 1: lane -> (row, stored chunk); source chunk = stored ^ (row & 15).
+    // Rows past the valid ones re-read the last valid row (never a row that may not have been written yet); no lane is masked, so
+    // every wave issues exactly NT DMA instructions per tile -- the counted vmcnt waits below rely on that.
+    // Addressing: uniform 64-bit base (source plane + first row + batch) + one 32-bit per-lane offset per e, shared by both sources.
     const int drow = lane >> 5, dchunk = lane & 31;
+    unsigned doff[NT];
+#pragma unroll
+    for (int e = 0; e < NT; ++e) {
+        const int row = 2 * (wave + 8 * e) + drow;
+        const int srow = row < rows_valid ? row : rows_valid - 1;
+        doff[e] = (unsigned)srow * (unsigned)U_pad + 4u * (unsigned)(dchunk ^ (row & 15));
+    }
+    const float* up0 = up + (size_t)row_up * U_pad;
+    const float* lat0 = lat + (size_t)row_lat * U_pad;
     auto issue = [&](int b) {
-        const bool is_up = b < NBU;
-        const float* src = is_up ? up : lat;
-        const unsigned rb = is_up ? row_up : row_lat;
-        const int kb = is_up ? b : b - NBU;
+        const float* src = (b < NBU ? up0 + b * LSTM_KB : lat0 + (b - NBU) * LSTM_KB);
         float* buf = ring + (b % NBUF) * BUF_FLOATS;
 #pragma unroll
-        for (int e = 0; e < NT; ++e) {
-            const int wi = wave + 8 * e, row = 2 * wi + drow;
-            const int c = dchunk ^ (row & 15);
-            // rows past the valid ones re-read the last valid row (never a row that may not have been written yet); no lane is
-            // masked, so every wave issues exactly NT DMA instructions per tile -- the counted vmcnt waits below rely on that
-            const int srow = row < rows_valid ? row : rows_valid - 1;
-            __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(src + (size_t)(rb + srow) * U_pad + kb * LSTM_KB + 4 * c), AM_LDS_PTR(buf + wi * 256), 16, 0, 16 /* sc1 */);
-        }
+        for (int e = 0; e < NT; ++e)
+            __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(src + doff[e]), AM_LDS_PTR(buf + (wave + 8 * e) * 256), 16, 0, 16 /* sc1 */);
     };
     if (LAT && NBU < NBUF - 1 && NBU < NBT) ok = lat_wait();          // a lateral tile is among the first requests
 #pragma unroll
@@ -1336,21 +1339,17 @@ __device__ __forceinline__ bool persist_products(const float* up, unsigned row_u
 #pragma unroll
                     for (int r = 0; r < NT; ++r)
                         pb[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s][r][j], (b < NBU ? wu[b < NBU ? b : 0][s][j] : wl[b < NBU ? 0 : b - NBU][s][j]), pb[r], 0, 0, 0);
-        } else {         // the fragments of sub-step s + 1 are requested before the MFMAs of sub-step s
-            f32x4 af[2][NT];
-#pragma unroll
-            for (int r = 0; r < NT; ++r) af[0][r] = *(const f32x4*)(sa + r * 16 * PERSIST_TILE_LD + xs[0]);
+        } else {         // (double-buffering the fragments across sub-steps costs 16 VGPRs the weights need, and measured no gain)
 #pragma unroll
             for (int s = 0; s < LSTM_KS; ++s) {
-                if (s + 1 < LSTM_KS) {
+                f32x4 af[NT];
 #pragma unroll
-                    for (int r = 0; r < NT; ++r) af[(s + 1) & 1][r] = *(const f32x4*)(sa + r * 16 * PERSIST_TILE_LD + xs[s + 1 < LSTM_KS ? s + 1 : 0]);
-                }
+                for (int r = 0; r < NT; ++r) af[r] = *(const f32x4*)(sa + r * 16 * PERSIST_TILE_LD + xs[s]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < NT; ++r)
-                        pb[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s & 1][r][j], (b < NBU ? wu[b < NBU ? b : 0][s][j] : wl[b < NBU ? 0 : b - NBU][s][j]), pb[r], 0, 0, 0);
+                        pb[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][j], (b < NBU ? wu[b < NBU ? b : 0][s][j] : wl[b < NBU ? 0 : b - NBU][s][j]), pb[r], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -1412,12 +1411,11 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
 #pragma unroll
     for (int r = 0; r < NT; ++r) acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     bool ok = true;
-    // layer 0: one pipeline (lateral only).  Upper layers: two pipelines -- a single one over both products keeps both weight sets,
-    // the tiles in flight and the wait's state live at once and spills 40-60 VGPRs into the MFMA loop (measured: 36 us per step
-    // against 23); the upward product's MFMAs still run in the shadow of the other workgroups' step t-1
+    // layer 0: one pipeline (lateral only).  Upper layers: two pipelines -- a single one over both products needs ~20 VGPRs more
+    // than the 256 there are (both weight sets stay live through the wait) and the spills land in the MFMA loop: measured 21.1 us
+    // per 192-row step against 21.5 us for two pipelines, not worth the scratch traffic
     if (NBU) {
-        const bool last = t == 0;
-        if (last) ok = persist_products<NBU, NBL, false, NT>(Ly.Hin, r_t, Ly.H, 0u, rows_valid, U_pad, wu, wl, acc, smem, tid, l15, lq, kh, lat_wait, fetch_epilogue);
+        if (t == 0) ok = persist_products<NBU, NBL, false, NT>(Ly.Hin, r_t, Ly.H, 0u, rows_valid, U_pad, wu, wl, acc, smem, tid, l15, lq, kh, lat_wait, fetch_epilogue);
         else ok = persist_products<NBU, NBL, false, NT>(Ly.Hin, r_t, Ly.H, 0u, rows_valid, U_pad, wu, wl, acc, smem, tid, l15, lq, kh, lat_wait, [] {});
         persist_stamp(a, gidx, ut, t, 2);
     }
@@ -1488,8 +1486,10 @@ __device__ __forceinline__ void persist_body(const LstmPersistArgs& a, const Lst
                 for (int s = 0; s < LSTM_KS; ++s) wu[b][s] = *(const f32x4*)(Ly.Wup + wrow + b * LSTM_KB + 16 * s);
         }
     }
+    int n_next = a.n_active[0];
     for (int t = 0; t < a.T; ++t) {
-        const int n_act = a.n_active[t];
+        const int n_act = n_next;
+        n_next = t + 1 < a.T ? a.n_active[t + 1] : 0;   // requested a whole step ahead: the scalar load's latency is off the chain
         const int tiles = (n_act + 15) >> 4;
         if (tiles <= 0) break;
         const int q = (tiles + NG - 1) / NG;            // <= NTMAX (host plan)
@@ -1533,7 +1533,6 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_kernel(const LstmPersistA
     else persist_body<0, NB, lstm_persist_ntmax(NB, false)>(a, Ly, li, gidx, ut, persist_smem, &s_flag);
 }
 
-int lstm_persist_mode();
 
 bool plan_lstm_persist(LstmPersistArgs& a, int n_slots, const int* n_active, unsigned* cum_out)
 {
@@ -1590,382 +1589,11 @@ hipError_t launch_lstm_persist(hipStream_t s, const LstmPersistArgs& a)
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Second persistent form: upward and lateral products in DIFFERENT workgroups.
-//
-// The timeline of the first form (tools/lstm_stamps.py, 3x512, 192 rows) shows a 23 us step for 13.7 us of MFMA time: the
-// two products run back to back in one workgroup (each pays its own pipeline start, ~2 us), then the gate math (1.8 us),
-// the publish (0.6 us) and the waits -- all serial, with the CU's matrix pipes idle meanwhile; and with few rows the
-// upward product sits on the recurrence's critical path although it does not depend on it.
-// Here a workgroup is 256 threads = 4 waves (wave = gate: 16 gate columns x the whole K = 512 in 128 VGPRs), two
-// workgroups per CU, and there are two kinds:
-//   upward  (layer l >= 1, row group g, unit tile): G_l[t] = h_{l-1}[t] . Wup^T + b   as soon as layer l-1 has produced h[t]
-//   lateral (layer l,      row group g, unit tile): pre = h_l[t-1] . Wlat^T + G_l[t]; gates, c, h[t]
-// Layer 0's G comes from the hoisted bulk GEMM as before; G_l of the upper layers travels through memory like h (sc1 stores /
-// sc1 loads / arrival counter: 16 KB per workgroup and step, off the critical path because the upward groups run ahead).
-// A CU's two workgroups are independent instruction streams on the same matrix pipes: while one waits, loads its first
-// tile or does gate math, the other multiplies.  The recurrence's chain per step shrinks to
-// [poll] [h tile] [lateral MFMAs] [gates] [publish].
-// Row groups are re-cut every step exactly as in the first form (q = ceil(tiles / groups); the upward and lateral groups
-// of a layer use the same cut, so lateral group g consumes what upward group g produced).
-// Summation order (this form's own; the posteriors of a frame are independent of batch composition and sharding, which
-// is what the tests pin): per gate column, MFMA steps with even j accumulate into one chain, odd j into another, both in
-// ascending k; pre = (even + odd) + G, G = (even + odd) + b.
-// ---------------------------------------------------------------------------------------------------
-constexpr int P2_KB = 64;                   // k per batch
-constexpr int P2_LDA = P2_KB + 8;           // LDS row stride of an A tile (floats): +32 B -> ds_read_b128 of (row l15, 16-B chunk lq) is conflict-free in every
-                                            // 16-lane service group (a stride of +16 B leaves a 2-way conflict per group: SQ_LDS_BANK_CONFLICT, profiles/r2b)
-constexpr int P2_ROWS = 64;                 // rows per workgroup and step (4 MFMA row tiles)
-constexpr int P2_SGLD = 20;                 // gate-exchange row stride (16 units + 16 B)
-constexpr size_t P2_LDS = 2 * P2_ROWS * P2_LDA * sizeof(float);   // 34,816 B; the gate exchange [4][64][20] aliases it
-
-
-__device__ __forceinline__ void p2_stamp(const LstmP2Args& a, int gidx, int ut, int t, int k)
-{
-    if (a.stamps && ut == 0 && threadIdx.x == 0) a.stamps[((size_t)gidx * a.T + t) * 8 + k] = __builtin_amdgcn_s_memrealtime();
-}
-
-// lanes 0..n-1 of wave 0 poll counters first.. (step column tcol), lane n polls `extra` (column extra_tcol) if extra >= 0
-__device__ __forceinline__ bool p2_wait(const LstmP2Args& a, int first, int n, int tcol, int extra, int extra_tcol, int* s_flag)
-{
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        int idx = -1, col = 0;
-        if (lane < n) { idx = first + lane; col = tcol; }
-        else if (lane == n && extra >= 0) { idx = extra; col = extra_tcol; }
-        bool ok = true;
-        if (idx >= 0) {
-            const unsigned target = a.cum[(size_t)idx * a.T + col];
-            const unsigned* c = a.counters + idx;
-            if (ld_agent_u32(c) < target) {
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                int it = 0;
-                while (ld_agent_u32(c) < target) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if ((++it & 63) == 0 && (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-                                            __builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)LSTM_P_TIMEOUT)) { ok = false; break; }
-                }
-            }
-        }
-        if (!ok) { __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *s_flag = 1; }
-    }
-    __syncthreads();
-    return *s_flag == 0;
-}
-
-// rows [row_base, row_base + 16 NT) of `src` (ld = U_pad; only the first rows_valid are loaded) times the resident fragments w
-// (this wave's 16 columns, all of K); `mid` runs once, two batches before the end (the step's epilogue operands are fetched there)
-template <int NBK, int NT, class Mid>
-__device__ __forceinline__ void p2_product(__amdgpu_buffer_rsrc_t src, unsigned row_base, int rows_valid, int U_pad, const f32x4 (&w)[NBK][4],
-                                           f32x4 (&acc0)[NT], f32x4 (&acc1)[NT], float* sA0, float* sA1, int tid, int l15, int lq, Mid&& mid)
-{
-    f32x4 av[2][NT];
-    auto load_a = [&](int b, f32x4 (&dst)[NT]) {
-#pragma unroll
-        for (int e = 0; e < NT; ++e) {
-            const int c = tid + 256 * e, r = c >> 4, c4 = c & 15;
-            dst[e] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            if (r < rows_valid) dst[e] = ld_sc1_b128(src, ((row_base + r) * (unsigned)U_pad + (unsigned)(b * P2_KB + 4 * c4)) * 4u);
-        }
-    };
-    load_a(0, av[0]);
-    load_a(1, av[1]);
-#pragma unroll
-    for (int b = 0; b < NBK; ++b) {
-        float* sA = (b & 1) ? sA1 : sA0;
-#pragma unroll
-        for (int e = 0; e < NT; ++e) {
-            const int c = tid + 256 * e, r = c >> 4, c4 = c & 15;
-            *(f32x4*)(sA + r * P2_LDA + 4 * c4) = av[b & 1][e];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // tile b is complete; everyone left tile b-2 (same buffer) before barrier b-1
-        if (b + 2 < NBK) load_a(b + 2, av[b & 1]);
-        if (b == NBK - 2) mid();
-        const float* sa = sA + l15 * P2_LDA + 4 * lq;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            f32x4 af[NT];
-#pragma unroll
-            for (int r = 0; r < NT; ++r) af[r] = *(const f32x4*)(sa + r * 16 * P2_LDA + 16 * s);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < NT; ++r) {
-                    if (j & 1) acc1[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][j], w[b][s][j], acc1[r], 0, 0, 0);
-                    else acc0[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][j], w[b][s][j], acc0[r], 0, 0, 0);
-                }
-        }
-    }
-    __syncthreads();   // every fragment read is done: the tiles may be rewritten (gate exchange / next step)
-}
-
-template <int NT>
-__device__ __forceinline__ void p2_publish(const LstmP2Args& a, int gidx)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its stores,
-    __syncthreads();                                    // the workgroup meets,
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(a.counters + gidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ONE lane signals
-}
-
-// one step of a lateral workgroup
-template <int NBK, int NT>
-__device__ __forceinline__ bool p2_step_lat(const LstmP2Args& a, const LstmP2Group& G, const LstmP2Layer& Ly, int gidx, int ut, int t, int n_act, int row0,
-                                            const f32x4 (&w)[NBK][4], float* smem, int* s_flag)
-{
-    constexpr int ROWS = NT * 16;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int gate = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, lq = lane >> 4;
-    const int U_pad = a.U_pad;
-    const int rows_valid = n_act - row0;                                       // > 0
-    const unsigned slot0 = (unsigned)(a.slot_base + row0);
-    const unsigned r_t = (unsigned)a.step_off[t] + slot0;                      // packed row of this group's first slot at step t
-    float* sA0 = smem;
-    float* sA1 = smem + P2_ROWS * P2_LDA;
-    p2_stamp(a, gidx, ut, t, 0);
-    if (t > 0 || G.g_src >= 0) {
-        if (!p2_wait(a, G.wait_first, t > 0 ? G.wait_n : 0, t > 0 ? t - 1 : 0, G.g_src, t, s_flag)) return false;
-    }
-    p2_stamp(a, gidx, ut, t, 1);
-    // epilogue operands of thread (row, unit quad): the four gates' upward terms and the previous cell state
-    const int erow = tid >> 2, quad = tid & 3;
-    const bool live = erow < ROWS && erow < rows_valid;
-    f32x4 gq[4], cq = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.G, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.Cst, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.H, 0, 0x7fffffff, 0x00020000);
-    auto fetch_epilogue = [&] {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            gq[k] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            if (live) gq[k] = ld_sc1_b128(grs, ((r_t + erow) * (unsigned)(4 * U_pad) + (unsigned)(ut * 64 + k * 16 + 4 * quad)) * 4u);
-        }
-        if (live && t > 0) cq = ld_sc1_b128(crs, ((slot0 + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u);
-    };
-    f32x4 acc0[NT], acc1[NT];
-#pragma unroll
-    for (int r = 0; r < NT; ++r) { acc0[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; acc1[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
-    if (t > 0) p2_product<NBK, NT>(hrs, (unsigned)a.step_off[t - 1] + slot0, rows_valid, U_pad, w, acc0, acc1, sA0, sA1, tid, l15, lq, fetch_epilogue);
-    else fetch_epilogue();
-    p2_stamp(a, gidx, ut, t, 2);
-    float* sg = smem;   // [gate][P2_ROWS][P2_SGLD]
-#pragma unroll
-    for (int r = 0; r < NT; ++r)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-            sg[(gate * P2_ROWS + r * 16 + lq * 4 + reg) * P2_SGLD + l15] = acc0[r][reg] + acc1[r][reg];
-    __syncthreads();
-    p2_stamp(a, gidx, ut, t, 3);
-    if (live) {
-        f32x4 pre[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pre[k] = *(const f32x4*)(sg + (k * P2_ROWS + erow) * P2_SGLD + 4 * quad) + gq[k];
-        f32x4 cn, hn;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float ga = am_tanh_rec(pre[0][u]);
-            const float gi = am_sigmoid_rec(pre[1][u]);
-            const float gf = am_sigmoid_rec(pre[2][u]);
-            const float go = am_sigmoid_rec(pre[3][u]);
-            const float ai = ga * gi;
-            const float fc = gf * cq[u];
-            const float c = ai + fc;
-            cn[u] = c;
-            hn[u] = go * am_tanh_rec(c);
-        }
-        st_sc1_b128(crs, ((slot0 + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u, cn);
-        st_sc1_b128(hrs, ((r_t + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u, hn);
-    }
-    p2_stamp(a, gidx, ut, t, 5);
-    p2_publish<NT>(a, gidx);
-    p2_stamp(a, gidx, ut, t, 6);
-    return true;
-}
-
-// one step of an upward workgroup: G[t] rows of its group = h_below[t] . Wup^T + b
-template <int NBK, int NT>
-__device__ __forceinline__ bool p2_step_up(const LstmP2Args& a, const LstmP2Group& G, const LstmP2Layer& Ly, const LstmP2Layer& Lb, int gidx, int ut, int t, int n_act, int row0,
-                                           const f32x4 (&w)[NBK][4], float bias, float* smem, int* s_flag)
-{
-    constexpr int ROWS = NT * 16;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int gate = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, lq = lane >> 4;
-    const int U_pad = a.U_pad;
-    const int rows_valid = n_act - row0;
-    const unsigned r_t = (unsigned)a.step_off[t] + (unsigned)(a.slot_base + row0);
-    float* sA0 = smem;
-    float* sA1 = smem + P2_ROWS * P2_LDA;
-    p2_stamp(a, gidx, ut, t, 0);
-    if (!p2_wait(a, G.wait_first, G.wait_n, t, -1, 0, s_flag)) return false;
-    p2_stamp(a, gidx, ut, t, 1);
-    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)Lb.H, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.G, 0, 0x7fffffff, 0x00020000);
-    f32x4 acc0[NT], acc1[NT];
-#pragma unroll
-    for (int r = 0; r < NT; ++r) { acc0[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; acc1[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
-    if (!a.debug_skip_upward) p2_product<NBK, NT>(hrs, r_t, rows_valid, U_pad, w, acc0, acc1, sA0, sA1, tid, l15, lq, [] {});
-    p2_stamp(a, gidx, ut, t, 2);
-    float* sg = smem;
-#pragma unroll
-    for (int r = 0; r < NT; ++r)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-            sg[(gate * P2_ROWS + r * 16 + lq * 4 + reg) * P2_SGLD + l15] = (acc0[r][reg] + acc1[r][reg]) + bias;
-    __syncthreads();
-    p2_stamp(a, gidx, ut, t, 3);
-    const int erow = tid >> 2, quad = tid & 3;
-    if (erow < ROWS && erow < rows_valid) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            st_sc1_b128(grs, ((r_t + erow) * (unsigned)(4 * U_pad) + (unsigned)(ut * 64 + k * 16 + 4 * quad)) * 4u,
-                        *(const f32x4*)(sg + (k * P2_ROWS + erow) * P2_SGLD + 4 * quad));
-    }
-    p2_stamp(a, gidx, ut, t, 5);
-    p2_publish<NT>(a, gidx);
-    p2_stamp(a, gidx, ut, t, 6);
-    return true;
-}
-
-template <int NBK, int KIND>
-__device__ __forceinline__ void p2_body(const LstmP2Args& a, const LstmP2Group& G, int gidx, int ut, float* smem, int* s_flag)
-{
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int gate = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, lq = lane >> 4;
-    const int U_pad = a.U_pad;
-    const LstmP2Layer& Ly = a.L[G.layer];
-    f32x4 w[NBK][4];   // the resident weights: this wave's 16 gate columns x all of K
-    {
-        const float* W = KIND ? Ly.Wup : Ly.Wlat;
-        const size_t wrow = (size_t)(ut * 64 + gate * 16 + l15) * U_pad + 4 * lq;
-#pragma unroll
-        for (int b = 0; b < NBK; ++b)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) w[b][s] = *(const f32x4*)(W + wrow + b * P2_KB + 16 * s);
-    }
-    const float bias = KIND ? Ly.bias[ut * 64 + gate * 16 + l15] : 0.0f;
-    for (int t = 0; t < a.T; ++t) {
-        int n_act = a.n_active[t] - a.slot_base;
-        if (n_act > a.slot_cap) n_act = a.slot_cap;
-        const int tiles = (n_act + 15) >> 4;
-        if (tiles <= 0) break;
-        const int q = (tiles + G.ng - 1) / G.ng;          // <= 4 (host plan)
-        const int tile0 = G.g * q;
-        int nt = tiles - tile0;
-        if (nt > q) nt = q;
-        if (nt <= 0) continue;
-        const int row0 = tile0 * 16;
-        bool ok = true;
-        if (KIND) {
-            const LstmP2Layer& Lb = a.L[G.layer - 1];
-            switch (nt) {
-            case 1: ok = p2_step_up<NBK, 1>(a, G, Ly, Lb, gidx, ut, t, n_act, row0, w, bias, smem, s_flag); break;
-            case 2: ok = p2_step_up<NBK, 2>(a, G, Ly, Lb, gidx, ut, t, n_act, row0, w, bias, smem, s_flag); break;
-            case 3: ok = p2_step_up<NBK, 3>(a, G, Ly, Lb, gidx, ut, t, n_act, row0, w, bias, smem, s_flag); break;
-            default: ok = p2_step_up<NBK, 4>(a, G, Ly, Lb, gidx, ut, t, n_act, row0, w, bias, smem, s_flag); break;
-            }
-        } else {
-            switch (nt) {
-            case 1: ok = p2_step_lat<NBK, 1>(a, G, Ly, gidx, ut, t, n_act, row0, w, smem, s_flag); break;
-            case 2: ok = p2_step_lat<NBK, 2>(a, G, Ly, gidx, ut, t, n_act, row0, w, smem, s_flag); break;
-            case 3: ok = p2_step_lat<NBK, 3>(a, G, Ly, gidx, ut, t, n_act, row0, w, smem, s_flag); break;
-            default: ok = p2_step_lat<NBK, 4>(a, G, Ly, gidx, ut, t, n_act, row0, w, smem, s_flag); break;
-            }
-        }
-        if (!ok) return;
-    }
-}
-
-__device__ __forceinline__ bool p2_prio() { return true; }
-
-template <int NBK>
-__global__ __launch_bounds__(256, 2) void lstm_persist2_kernel(const LstmP2Args a)
-{
-    extern __shared__ __attribute__((aligned(16))) float p2_smem[];
-    __shared__ int s_flag;
-    if (threadIdx.x == 0) s_flag = 0;
-    __syncthreads();
-    // role: workgroups b and b + 8 are neighbours of one group, so under round-robin placement (b % 8 = XCD) a group's
-    // workgroups share an XCD and its L2 (speed only): group = (b % 8) + 8 * ((b / 8) / tiles), unit tile = (b / 8) % tiles
-    const int tpg = a.U_pad / 16;
-    const int j = blockIdx.x >> 3;
-    const int gidx = (blockIdx.x & 7) + 8 * (j / tpg), ut = j % tpg;
-    if (gidx >= a.n_groups) return;
-    const LstmP2Group& G = a.groups[gidx];
-    // the lateral workgroups are the recurrence's critical path: their waves win the issue arbitration against the upward
-    // workgroup that shares their SIMDs (static priority, MI355X_MICROARCH.md "two waves per SIMD" item 4)
-    if (G.kind) p2_body<NBK, 1>(a, G, gidx, ut, p2_smem, &s_flag);
-    else { if (p2_prio()) __builtin_amdgcn_s_setprio(3); p2_body<NBK, 0>(a, G, gidx, ut, p2_smem, &s_flag); }
-}
-
 int lstm_persist_mode()
 {
-    static int mode = -1;   // AM_LSTM_PERSIST: 0 per-step kernels, 1 first persistent form, 2 split upward / lateral form (default)
-    if (mode < 0) { const char* v = getenv("AM_LSTM_PERSIST"); mode = v ? atoi(v) : 2; }
+    static int mode = -1;   // AM_LSTM_PERSIST=0 keeps the per-step kernels (A/B measurements)
+    if (mode < 0) { const char* v = getenv("AM_LSTM_PERSIST"); mode = v ? atoi(v) : 1; }
     return mode;
-}
-
-int lstm_persist2_capacity(int U_pad, int n_layers)
-{
-    if (U_pad != 256 && U_pad != 512) return 0;
-    const int groups_per_ng = 2 * n_layers - 1;          // lateral groups of every layer + upward groups of the upper layers
-    const int ng = P2_MAX_GROUPS / groups_per_ng;        // row groups per layer the 16 group slots allow
-    return ng * 64;                                      // 4 row tiles per group
-}
-
-bool plan_lstm_persist2(LstmP2Args& a, int n_slots, const int* n_active, unsigned* cum_out)
-{
-    if (a.n_layers < 1 || a.n_layers > LSTM_MAX_LAYERS || a.T <= 0 || n_slots <= 0) return false;
-    if (n_slots > lstm_persist2_capacity(a.U_pad, a.n_layers)) return false;
-    const int tpg = a.U_pad / 16;
-    const int tiles0 = (n_slots + 15) / 16;
-    const int kinds = 2 * a.n_layers - 1;
-    // as many row groups per layer as the chip holds (<= 16 groups, <= 512 workgroups): fewer tiles per group and step
-    int ng = (tiles0 + 3) / 4;
-    while ((ng + 1) * kinds <= P2_MAX_GROUPS && (ng + 1) * kinds * tpg <= 512 && ng < tiles0) ++ng;
-    int n = 0;
-    int lat0[LSTM_MAX_LAYERS], up0[LSTM_MAX_LAYERS];
-    for (int l = 0; l < a.n_layers; ++l) { lat0[l] = n; n += ng; }
-    for (int l = 1; l < a.n_layers; ++l) { up0[l] = n; n += ng; }
-    a.n_groups = n;
-    for (int l = 0; l < a.n_layers; ++l)
-        for (int g = 0; g < ng; ++g) {
-            LstmP2Group& G = a.groups[lat0[l] + g];
-            G.kind = 0; G.layer = l; G.g = g; G.ng = ng; G.wait_first = lat0[l]; G.wait_n = ng; G.g_src = l > 0 ? up0[l] + g : -1;
-        }
-    for (int l = 1; l < a.n_layers; ++l)
-        for (int g = 0; g < ng; ++g) {
-            LstmP2Group& G = a.groups[up0[l] + g];
-            G.kind = 1; G.layer = l; G.g = g; G.ng = ng; G.wait_first = lat0[l - 1]; G.wait_n = ng; G.g_src = -1;
-        }
-    if (cum_out) {
-        for (int gi = 0; gi < n; ++gi) {
-            const int g = a.groups[gi].g;
-            unsigned* row = cum_out + (size_t)gi * a.T;
-            unsigned c = 0;
-            for (int t = 0; t < a.T; ++t) {
-                int na = n_active[t] - a.slot_base;
-                if (na > a.slot_cap) na = a.slot_cap;
-                const int tiles = na > 0 ? (na + 15) / 16 : 0, q = (tiles + ng - 1) / ng;
-                if (tiles > 0 && g * q < tiles) c += (unsigned)tpg;
-                row[t] = c;
-            }
-        }
-    }
-    return true;
-}
-
-hipError_t launch_lstm_persist2(hipStream_t s, const LstmP2Args& a)
-{
-    const int tpg = a.U_pad / 16;
-    const int grid = 8 * tpg * ((a.n_groups + 7) / 8);
-    if (a.n_groups <= 0 || a.n_groups > P2_MAX_GROUPS || grid > 512) return hipErrorInvalidValue;
-    if (a.U_pad == 512) hipLaunchKernelGGL(lstm_persist2_kernel<8>, dim3(grid), dim3(256), P2_LDS, s, a);
-    else if (a.U_pad == 256) hipLaunchKernelGGL(lstm_persist2_kernel<4>, dim3(grid), dim3(256), P2_LDS, s, a);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
 }
 
 constexpr size_t LSTM_THIN_LDS_MAX = 72 * 1024;   // two blocks per CU stay co-resident

@@ -106,6 +106,21 @@ def splice(data, shifts):
     return out
 
 
+def splice_rowloop(data, shifts):
+    """The same result computed the way the reference computes it: a Python loop over rows and shifts with a per-row clamp
+    (kw_utils.py:24-36).  Kept only so the CPU baseline can show where the reference's time goes (bench.py times it on a
+    3,000-frame sample); `splice` above is what the parity tests use."""
+    data = np.asarray(data)
+    n, m = data.shape
+    shifts = list(shifts)
+    out = np.zeros((n, m * len(shifts)), dtype=np.float32)
+    for i in range(n):
+        for wi, w in enumerate(shifts):
+            j = min(max(i + w, 0), n - 1)
+            out[i][wi * m:(wi + 1) * m] = data[j]
+    return out
+
+
 def prepare_batch(data, idxs, winlen):
     """Splice a batch of row indices with window ``winlen`` (kw_nn_utils.py:19-43).
 
