@@ -160,6 +160,7 @@ struct am_pipeline {
     DevBuf d_stamps;                    // AM_LSTM_STAMPS=1: timeline of the last member's persistent launch (am_lstm_stamps)
     int stamps_groups = 0, stamps_T = 0;
     bool used_persist = false;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // second-stream overlap of the output layer with the recurrence's tail
     // the recurrent launch sequence (thousands of ~2 us kernels) is replayed from a hipGraph from the 2nd run on
     int lstm_runs = 0;
     hipGraph_t graph = nullptr;
@@ -714,6 +715,8 @@ extern "C" int am_pipeline_destroy(am_pipeline* p)
     (void)hipStreamSynchronize(p->e->stream);
     (void)hipStreamSynchronize(p->e->stream2);
     for (auto ev : p->chunk_done) (void)hipEventDestroy(ev);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     p->drop_graph();
     for (DevBuf* d : {&p->d_shifts, &p->d_add, &p->d_scale, &p->d_rplw, &p->d_rplb, &p->d_rpllb, &p->d_prior, &p->d_x, &p->d_ivec, &p->d_in, &p->d_in_s,
                       &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c, &p->d_nact, &p->d_stepoff, &p->d_sync, &p->d_stamps})
@@ -850,18 +853,20 @@ static int member_finish(am_pipeline* p, int mi, int64_t rows)
     return run_kernel(p->e, K_FINISH, [&] { return launch_finish(p->e->stream, f); });
 }
 
-static int final_finish(am_pipeline* p, int64_t rows, float* out, const int* row_map)
+static int final_finish(am_pipeline* p, int64_t rows, float* out, const int* row_map, int64_t row0 = 0, hipStream_t on = nullptr)
 {
+    // rows [row0, row0 + rows) of the accumulated logits; with a row_map the output row is row_map[row], else out + row (caller offsets `out`)
     am_model* m0 = p->members[0];
     FinishArgs f{};
-    f.in = (p->combine == AM_COMBINE_LOGPOST ? p->d_acc2 : p->d_acc).as<float>(); f.ldin = p->acc_ld;
-    f.out = out; f.ldout = m0->C; f.row_map = row_map;
+    f.in = (p->combine == AM_COMBINE_LOGPOST ? p->d_acc2 : p->d_acc).as<float>() + row0 * p->acc_ld; f.ldin = p->acc_ld;
+    f.out = out; f.ldout = m0->C; f.row_map = row_map ? row_map + row0 : nullptr;
     f.n = rows; f.C = m0->C;
     f.divisor = final_divisor(p);
     if (p->has_rpl) { f.rpl_w = p->d_rplw.as<float>(); f.rpl_b = p->d_rplb.as<float>(); f.rpl_lb = p->d_rpllb.as<float>(); }
     if (p->has_prior) f.prior = p->d_prior.as<float>();
     f.normalise = p->normalise;
-    return run_kernel(p->e, K_FINISH, [&] { return launch_finish(p->e->stream, f); });
+    hipStream_t st = on ? on : p->e->stream;
+    return run_kernel(p->e, K_FINISH, [&] { return launch_finish(st, f); }, st);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -1346,7 +1351,11 @@ extern "C" int am_lstm_run(am_pipeline* p)
     p->results_valid = true;   // (cleared again below if the enqueue fails)
     if (p->n_packed == 0) return AM_OK;
     auto eager = [&] { const int rc = lstm_enqueue(p); if (rc != AM_OK) p->results_valid = false; return rc; };
-    if (e->profile || !lstm_use_graph()) return eager();   // per-kernel events need eager launches
+    // with the persistent form a pass is a handful of launches on two streams: nothing to gain from a graph, and a replayed
+    // graph serialises the second stream's branch (measured: 10.2 ms replayed against 8.8 ms eager)
+    bool all_persistent = !p->persist.empty();
+    for (size_t mi = 0; mi < p->members.size() && all_persistent; ++mi) all_persistent = mi < p->persist.size() && p->persist[mi].form == 1;
+    if (e->profile || all_persistent || !lstm_use_graph()) return eager();   // per-kernel events need eager launches
     if (p->graph_exec) { HIP_TRY(hipGraphLaunch(p->graph_exec, e->stream)); return AM_OK; }
     if (p->lstm_runs++ == 0) return eager();          // one-shot use: eager (no capture / instantiate cost)
     // second run on the same upload: capture the launch sequence once, then replay it
@@ -1451,6 +1460,7 @@ static int lstm_enqueue(am_pipeline* p)
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)p->d_out.p, bits, (size_t)p->n * m0->C, e->stream));
     }
     p->used_persist = false;
+    int64_t split_rows = 0, split_step = 0;   // > 0: the output layer of rows [0, split_rows) runs on the second stream, beside the recurrence's tail
     if (p->d_sync.p) HIP_TRY(hipMemsetAsync(p->d_sync.p, 0, sizeof(unsigned) * 64, e->stream));
     GatherArgs ga{};
     ga.x = p->d_x.as<float>(); ga.ivec = p->has_ivec ? p->d_ivec.as<float>() : nullptr; ga.src = p->d_src.as<int>();
@@ -1499,7 +1509,24 @@ static int lstm_enqueue(am_pipeline* p)
                 p->stamps_groups = pa.n_groups_total; p->stamps_T = pa.T;
             }
             HIP_TRY(hipMemsetAsync(p->d_sync.p, 0, sizeof(unsigned) * 63, e->stream));   // the abort flag (last word) is cleared once per pass
+            // Overlap of the output layer with the recurrence's tail (single network, logit output): from the step t_A at which at
+            // most 32 utterances are still running, two thirds of the persistent kernel's workgroups have no rows left and
+            // leave.  The output GEMM + log-softmax of the rows of steps < t_A go to the second stream behind a one-wave gate
+            // kernel that returns when the top layer has finished step t_A - 1; they take the CUs as those are vacated.
+            static const bool overlap_ok = env_int("AM_LSTM_OVERLAP", 1) != 0;
+            if (overlap_ok && !e->profile && p->members.size() == 1 && p->combine == AM_COMBINE_LOGITS) {
+                int64_t tA = -1;
+                for (int64_t t = 1; t < T; ++t) if (p->n_active[t] <= 32) { tA = t; break; }
+                const int64_t RA = tA > 0 ? p->step_off[tA] / GEMM_BM * GEMM_BM : 0;
+                if (RA >= NP / 4 && RA < rows_pad) { split_rows = RA; split_step = tA; }
+            }
+            if (split_rows > 0) {
+                if (!p->ev_fork) { HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming)); }
+                HIP_TRY(hipEventRecord(p->ev_fork, e->stream));            // the counters are zero from here on
+                HIP_TRY(hipStreamWaitEvent(e->stream2, p->ev_fork, 0));
+            }
             AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_persist(e->stream, pa); }));
+            if (split_rows > 0) AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_gate(e->stream2, pa, NL - 1, (int)split_step - 1); }, e->stream2));
             p->used_persist = true;
         } else
         // wavefront over (layer, time): launch d runs layer l at t = d - l; chain length T + NL - 1 instead of T * NL
@@ -1530,6 +1557,20 @@ static int lstm_enqueue(am_pipeline* p)
         g.A = A; g.lda = lda; g.W = Lo.W.as<float>(); g.ldw = Lo.in_pad; g.bias = Lo.b.as<float>();
         g.C = p->d_acc.as<float>(); g.ldc = m->C_pad; g.M_pad = (int)rows_pad; g.N_pad = Lo.out_pad; g.K_pad = Lo.in_pad;
         g.epi = epilogue_mode(p, mi, &g.alpha);
+        if (split_rows > 0) {
+            // rows of the finished steps: second stream (gate kernel in front); the rest: compute stream, after the recurrence
+            GemmArgs ga = g;
+            ga.M_pad = (int)split_rows;
+            ga.queue = p->d_sync.as<int>() + 62;   // zeroed with the arrival counters, before the fork
+            AM_TRY(run_kernel(e, K_GEMM_OUT, [&] { return launch_gemm(e->stream2, ga); }, e->stream2));
+            AM_TRY(final_finish(p, split_rows, p->d_out.as<float>(), p->d_dst.as<int>(), 0, e->stream2));
+            HIP_TRY(hipEventRecord(p->ev_join, e->stream2));
+            g.A += (size_t)split_rows * lda; g.C += (size_t)split_rows * m->C_pad; g.M_pad = (int)(rows_pad - split_rows);
+            AM_TRY(run_kernel(e, K_GEMM_OUT, [&] { return launch_gemm(e->stream, g); }));
+            AM_TRY(final_finish(p, NP - split_rows, p->d_out.as<float>(), p->d_dst.as<int>(), split_rows));
+            HIP_TRY(hipStreamWaitEvent(e->stream, p->ev_join, 0));
+            return AM_OK;
+        }
         AM_TRY(run_kernel(e, K_GEMM_OUT, [&] { return launch_gemm(e->stream, g); }));
         if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(member_finish(p, mi, NP));
     }

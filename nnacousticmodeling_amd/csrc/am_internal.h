@@ -40,6 +40,7 @@ struct GemmArgs {
     int act;                      // AM_ACT_* (EPI_ACT only)
     int epi; float alpha;
     int row_p = 0, row_skip = 0;  // TDNN: output row R reads A row R + (R / row_p) * row_skip (0 = plain GEMM)
+    int* queue = nullptr;         // work-queue mode: device counter (zero before the launch) the blocks pull tile numbers from
 };
 hipError_t init_kernels();  // once per device after hipSetDevice
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
@@ -146,6 +147,7 @@ struct LstmPersistArgs {
 bool plan_lstm_persist(LstmPersistArgs& a, int n_slots, const int* n_active_host, unsigned* cum_out /*nullable*/);
 size_t lstm_persist_cum_size(const LstmPersistArgs& a);   // entries of `cum`
 hipError_t launch_lstm_persist(hipStream_t s, const LstmPersistArgs& a);
+hipError_t launch_lstm_gate(hipStream_t s, const LstmPersistArgs& a, int layer, int tcol);   // returns once `layer` has finished step tcol
 
 int lstm_persist_mode();   // AM_LSTM_PERSIST: 0 per-step kernels, 1 (default) the persistent form
 

@@ -100,7 +100,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NI], const
 template <int BN, int BK>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ bias,
-    float* __restrict__ C, int ldc, int tiles_n, int nk, int act, int epi, float alpha, int row_p, int row_skip)
+    float* __restrict__ C, int ldc, int tiles_n, int nk, int act, int epi, float alpha, int row_p, int row_skip, int* __restrict__ queue, int n_tiles)
 {
     constexpr int BM = GEMM_BM, NW = GEMM_WM * GEMM_WN;
     constexpr int MI = BM / GEMM_WM / 32, NI = BN / GEMM_WN / 32;
@@ -119,9 +119,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(
 
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous run
     // of tiles, n fastest, so the blocks resident on one XCD share A panels and W in its L2.
+    // Work-queue mode (queue != nullptr): the blocks pull tiles from a global counter instead.  Workgroups are dealt to the XCDs
+    // statically, so when other kernels hold some XCDs (the persistent recurrent kernel's last row groups), the blocks dealt to
+    // the free XCDs do ALL the work and the late-comers find the queue empty; which block computes a tile never changes a bit.
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
-    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    for (;;) {
+    if (queue) {           // the tile number travels through the first word of the (idle) stage buffers: no LDS beyond the stages' (two blocks per CU use all 160 KiB)
+        __syncthreads();   // the previous tile's LDS reads are done
+        if (threadIdx.x == 0) *(volatile int*)smem = atomicAdd(queue, 1);
+        __syncthreads();
+        tile = *(volatile int*)smem;
+        __syncthreads();   // everyone has read it before the first LDS-DMA piece lands there
+        if (tile >= n_tiles) break;
+    }
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -214,6 +226,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(
     } else if (epi == EPI_LINEAR) gemm_epilogue<3, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
     else if (epi == EPI_SCALE) gemm_epilogue<4, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
     else gemm_epilogue<5, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
+    if (!queue) break;
+    }
 }
 
 constexpr int GEMM_LDS_256 = 2 * (GEMM_BM + 256) * 32 * 4;  // 128 KiB
@@ -249,13 +263,15 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g)
     if (g.M_pad % GEMM_BM || g.K_pad % GEMM_BK || g.M_pad <= 0 || g.K_pad <= 0) return hipErrorInvalidValue;
     const int tiles_m = g.M_pad / GEMM_BM;
     if (g.N_pad % 256 == 0) {
-        const int tiles_n = g.N_pad / 256;
-        hipLaunchKernelGGL((gemm_nt_f32_kernel<256, 32>), dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), GEMM_LDS_256, s,
-                           g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 32, g.act, g.epi, g.alpha, g.row_p, g.row_skip);
+        const int tiles_n = g.N_pad / 256, n_tiles = tiles_m * tiles_n;
+        const int grid = g.queue ? std::min(n_tiles, 256) : n_tiles;     // work-queue mode: one block per CU slot is enough
+        hipLaunchKernelGGL((gemm_nt_f32_kernel<256, 32>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_256, s,
+                           g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 32, g.act, g.epi, g.alpha, g.row_p, g.row_skip, g.queue, n_tiles);
     } else if (g.N_pad % 384 == 0) {
-        const int tiles_n = g.N_pad / 384;
-        hipLaunchKernelGGL((gemm_nt_f32_kernel<384, 16>), dim3(tiles_m * tiles_n), dim3(GEMM_THREADS), GEMM_LDS_384, s,
-                           g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 16, g.act, g.epi, g.alpha, g.row_p, g.row_skip);
+        const int tiles_n = g.N_pad / 384, n_tiles = tiles_m * tiles_n;
+        const int grid = g.queue ? std::min(n_tiles, 512) : n_tiles;
+        hipLaunchKernelGGL((gemm_nt_f32_kernel<384, 16>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_384, s,
+                           g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 16, g.act, g.epi, g.alpha, g.row_p, g.row_skip, g.queue, n_tiles);
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -1578,6 +1594,34 @@ bool plan_lstm_persist(LstmPersistArgs& a, int n_slots, const int* n_active, uns
 }
 
 size_t lstm_persist_cum_size(const LstmPersistArgs& a) { return (size_t)a.n_groups_total * a.T; }
+
+// One wave that returns once the `n` groups first.. have reached their step-`tcol` arrival targets (bounded like every other wait).
+// Launched on a second stream in front of the output layer's GEMM for the rows of steps <= tcol: as the persistent kernel's
+// workgroups run out of rows and leave, that GEMM takes over their CUs while the few remaining utterances are still stepping.
+__global__ __launch_bounds__(64) void lstm_gate_kernel(const unsigned* counters, const unsigned* cum, int T, int first, int n, int tcol, int* abort_flag)
+{
+    const int lane = threadIdx.x;
+    if (lane >= n) return;
+    const unsigned target = cum[(size_t)(first + lane) * T + tcol];
+    const unsigned* c = counters + first + lane;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int it = 0;
+    while (ld_agent_u32(c) < target) {
+        __builtin_amdgcn_s_sleep(8);
+        if ((++it & 63) == 0 && (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                                __builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)LSTM_P_TIMEOUT)) {
+            __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+
+hipError_t launch_lstm_gate(hipStream_t s, const LstmPersistArgs& a, int layer, int tcol)
+{
+    if (layer < 0 || layer >= a.n_layers || tcol < 0 || tcol >= a.T) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lstm_gate_kernel, dim3(1), dim3(64), 0, s, a.counters, a.cum, a.T, a.L[layer].group0, a.L[layer].n_groups, tcol, a.abort_flag);
+    return hipGetLastError();
+}
 
 hipError_t launch_lstm_persist(hipStream_t s, const LstmPersistArgs& a)
 {
