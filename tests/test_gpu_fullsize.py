@@ -83,6 +83,30 @@ def test_lstm_config_size(engine, real_ft_path):
         assert np.array_equal(p.lstm_download(), whole)
 
 
+def test_recurrent_forms_agree_bit_for_bit(engine, real_ft_path):
+    """The recurrent stack has two kernel forms: the persistent one (one launch, weights resident in registers; stacks of 256 or
+    512 units with at most 192 utterance slots at 3 layers) and the per-step kernels (everything else).  Both use the same
+    summation order and gate functions, so a frame's posteriors must not depend on the form: a 230-utterance file (per-step
+    kernels) against the same file cut into two halves of 115 utterances (persistent kernel), for 512- and 256-unit stacks,
+    plus the oracle on a sample of utterances."""
+    ft = orc.centre_frame_transform(orc.load_kaldi_feature_transform(real_ft_path))
+    for units, layers, seed in ((512, 3, 7), (256, 2, 8)):
+        rng = np.random.default_rng(seed)
+        params = orc.make_lstm_params(rng, 40, units, layers, 1909)
+        off = orc.make_offsets(rng, 230, 23000, lo=20, hi=260)
+        x = rng.standard_normal((23000, 40)).astype(np.float32)
+        p = _pipe(engine, "lstm", layers, params, ft, [0])
+        whole = p.forward_lstm(x, off, timedelay=2)
+        cut = 115
+        a = p.forward_lstm(x[:off[cut]], off[:cut + 1], timedelay=2)
+        b = p.forward_lstm(x[off[cut]:], off[cut:] - off[cut], timedelay=2)
+        assert np.array_equal(np.concatenate([a, b]), whole)
+        k = 6
+        want = orc.predict(orc.LSTM(params, layers), x[:off[k]], off[:k + 1], True, 1, 2, ft)
+        assert np.max(np.abs(whole[:off[k]] - want)) <= TOL
+        p.close()
+
+
 def test_edge_cases(engine, real_ft_path):
     rng = np.random.default_rng(5)
     ft = orc.load_kaldi_feature_transform(real_ft_path)
@@ -168,8 +192,8 @@ def test_threaded_multi_shard_runner_on_one_gpu(real_ft_path, real_priors):
             ftc = orc.centre_frame_transform(ft)
             off = orc.make_offsets(rng, 40, 6000, lo=40, hi=400)
             xr = rng.standard_normal((6000, 40)).astype(np.float32)
-            lp = [orc.make_lstm_params(rng, 40, 128, 2, 1909) for _ in range(3)]
-            ls = [networks.get_nn("lstm", 2, [128], 1909).set_params(q) for q in lp]
+            lp = [orc.make_lstm_params(rng, 40, 256, 2, 1909) for _ in range(3)]   # 256 units: the persistent recurrent kernel, three of them at once
+            ls = [networks.get_nn("lstm", 2, [256], 1909).set_params(q) for q in lp]
             a = one.forward_lstm(ls[0], xr, off, ft=ftc, timedelay=3)
             b = three.forward_lstm(ls[0], xr, off, ft=ftc, timedelay=3)
             assert len(three._state) == 3 and np.array_equal(a, b)
