@@ -164,7 +164,7 @@ int am_pipeline_set_normalise(am_pipeline* p, int on);
  * unless the shard touches the start/end of the file (global clamp, kw_utils.py:29-33).
  * ivec: [n, d_iv] or NULL.  am_ff_upload copies to HBM; am_ff_run launches the whole device path on the
  * compute stream (asynchronous); am_ff_download copies y [n, C] back and synchronises.
- * am_forward_ff = upload, then the device path in 65,536-row chunks with the download of chunk c overlapping the
+ * am_forward_ff = upload, then the device path in 16,384-row chunks (AM_FF_PIPE_ROWS) with the download of chunk c overlapping the
  * compute of chunk c+1 on a separate stream (same results).  Replaces the FF branch of predict (predict_folds.py:69-94) and of
  * evaluateModelTestTri (evaluateModelForTest.py:98-112). */
 int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, int64_t n, int halo_lo, int halo_hi);
@@ -179,7 +179,15 @@ int am_forward_ff(am_pipeline* p, const float* x, const float* ivec, int64_t n, 
  * stores a step only for utterances whose un-padded length exceeds t (predict_folds.py:50,61), so the last
  * `timedelay` output frames of every utterance are exactly 0 (or -log C after the dev-mode renormalisation of
  * AM_COMBINE_LOGPOST, predict_folds.py:219) -- reproduced here.  Pass 0 for the evaluate
- * behaviour (evaluateModelForTest.py:67-80).  y: [N, C] in file order. */
+ * behaviour (evaluateModelForTest.py:67-80).  y: [N, C] in file order.
+ * Replaces the time loops of predict (predict_folds.py:28-68) and evaluateModelTestTri (evaluateModelForTest.py:52-94).
+ * am_lstm_run is asynchronous.  LSTM stacks of 256 or 512 units whose row groups fit the chip (<= 192 utterances at three
+ * 512-unit layers) run as ONE persistent launch with the weights resident in registers (lstm_persist_kernel); every other
+ * shape, and the GRU / MGRU / peephole cells, run one launch per time step of the (layer, time) wavefront.  Both forms give
+ * the same bits.  The persistent kernel's inter-workgroup waits are bounded (2 s): if one ever times out the pass is marked
+ * invalid and am_lstm_download / am_decode_pipeline return AM_EHIP instead of hanging the GPU.
+ * Environment switches (measurement only): AM_LSTM_PERSIST=0 per-step kernels only; AM_LSTM_OVERLAP=0 no second-stream
+ * overlap of the output layer with the recurrence's tail; AM_LSTM_GRAPH=0|1 hipGraph replay of the per-step form. */
 int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec, const int64_t* offsets, int n_utts, int timedelay);
 int am_lstm_run(am_pipeline* p);
 int am_lstm_download(am_pipeline* p, float* y);

@@ -1,7 +1,7 @@
 // gfx950 (MI355X / CDNA4) kernels of the acoustic-model posterior engine.
 //
 // All buffers are laid out by the host layer so that the kernels need no bounds checks in their main loops:
-// activation matrices have M padded to 128 rows and their leading dimension padded to the next layer's K_pad,
+// activation matrices have M padded to 256 rows (GEMM_BM) and their leading dimension padded to the next layer's K_pad,
 // weights are zero-padded to [N_pad, K_pad].  Wavefront = 64 lanes everywhere.
 #include "am_internal.h"
 #include <algorithm>
@@ -1685,8 +1685,6 @@ hipError_t launch_lstm_wavefront(hipStream_t s, LstmWavefrontArgs& a)
     int max_tiles = 0;
     for (int l = 0; l < a.n; ++l) max_tiles = std::max(max_tiles, (a.L[l].n_active + 15) / 16);
     if (max_tiles == 0) return hipSuccess;
-    // measured per launch (3x512, graph replay): <= 16 rows 9.4 us thin vs 15 us wide; <= 32 rows 13.5 vs 15.5;
-    // at 33..64 rows the thin form (4 row tiles, A re-read by every block) loses, 18.3 vs 17 us
     // measured per launch (3x512, graph replay): <= 16 rows 9.4 us thin vs 15 us wide; <= 32 rows 13.5 vs 15.5;
     // at 33..64 rows the thin form (4 row tiles, A re-read by every block) loses, 18.3 vs 17 us
     int nc_max = 0;   // 64-k chains of the longest K in this launch: the thin kernel keeps one partial tile per chain in LDS

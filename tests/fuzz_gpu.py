@@ -73,7 +73,8 @@ def ensemble_case(eng, rng, it):
 def one(eng, rng, ft_full, it):
     if rng.random() < 0.2:
         return ensemble_case(eng, rng, it)
-    kind = rng.choice(["ff", "tdnn", "lstm", "gru", "mgrurelu", "mgrurelur", "peepholelstm"])
+    kinds = os.environ.get("FUZZ_KINDS", "ff,tdnn,lstm,gru,mgrurelu,mgrurelur,peepholelstm").split(",")   # e.g. FUZZ_KINDS=lstm
+    kind = rng.choice(kinds)
     D = int(rng.choice([40, 40, 24, 13]))
     C = int(rng.choice([1909, 39, 257, 600]))
     prior = (0.3 * rng.standard_normal(C)).astype(np.float32) if rng.random() < 0.5 else None
@@ -126,7 +127,7 @@ def one(eng, rng, ft_full, it):
             p.set_prior(prior)
             got = p.forward_ff(x)
     else:
-        n_utts = int(rng.choice([1, 3, 17, 33, 70]))
+        n_utts = int(rng.choice([1, 3, 17, 33, 70, 150, 192, 200]))
         lens = rng.integers(1, 60, n_utts)
         offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
         n = int(offsets[-1])
