@@ -152,8 +152,9 @@ struct am_pipeline {
     // persistent form of the LSTM stack (lstm_persist_kernel): per member the group plan + arrival table, shared step tables
     struct PersistPlan {
         int form = 0;                       // 0 per-step kernels, 1 lstm_persist_kernel
-        LstmPersistArgs args{}; DevBuf cum;
-        void release() { cum.release(); form = 0; }
+        std::vector<LstmPersistArgs> chunks;   // one launch per chunk of utterance slots (utterances are independent; longest first)
+        std::vector<DevBuf> cums;
+        void release() { for (auto& c : cums) c.release(); cums.clear(); chunks.clear(); form = 0; }
     };
     std::vector<PersistPlan> persist;
     DevBuf d_nact, d_stepoff, d_sync;   // int [T], int [T + 1], unsigned [groups + 1] (arrival counters, abort flag last)
@@ -1313,14 +1314,21 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
             if (!fits) continue;
             auto& pl = p->persist[mi];
             const int U_pad = m->L[0].U_pad;
-            pl.args = LstmPersistArgs{};
-            pl.args.n_layers = m->n_layers; pl.args.U_pad = U_pad; pl.args.T = (int)T;
-            if (!plan_lstm_persist(pl.args, n_utts, nact.data(), nullptr)) continue;
-            staging.emplace_back(lstm_persist_cum_size(pl.args));
-            plan_lstm_persist(pl.args, n_utts, nact.data(), staging.back().data());
-            AM_TRY(pl.cum.ensure(sizeof(unsigned) * staging.back().size()));
-            HIP_TRY(hipMemcpyAsync(pl.cum.p, staging.back().data(), sizeof(unsigned) * staging.back().size(), hipMemcpyHostToDevice, e->stream));
-            pl.form = 1;
+            const int cap = lstm_persist_capacity(U_pad, m->n_layers);
+            if (cap <= 0) continue;
+            bool ok = true;
+            for (int base = 0; base < n_utts && ok; base += cap) {
+                LstmPersistArgs pa{};
+                pa.n_layers = m->n_layers; pa.U_pad = U_pad; pa.T = (int)T; pa.slot_base = base; pa.slot_cap = std::min(cap, n_utts - base);
+                if (!plan_lstm_persist(pa, pa.slot_cap, nact.data(), nullptr)) { ok = false; break; }
+                staging.emplace_back(lstm_persist_cum_size(pa));
+                plan_lstm_persist(pa, pa.slot_cap, nact.data(), staging.back().data());
+                pl.cums.emplace_back();
+                AM_TRY(pl.cums.back().ensure(sizeof(unsigned) * staging.back().size()));
+                HIP_TRY(hipMemcpyAsync(pl.cums.back().p, staging.back().data(), sizeof(unsigned) * staging.back().size(), hipMemcpyHostToDevice, e->stream));
+                pl.chunks.push_back(pa);
+            }
+            if (ok) pl.form = 1; else pl.release();
         }
         AM_TRY(sync_all(e));   // the staging vectors go out of scope here
     }
@@ -1488,45 +1496,48 @@ static int lstm_enqueue(am_pipeline* p)
         float* Hall = p->d_H.as<float>();
         float* Call = p->d_c.as<float>();
         if (p->persist[mi].form == 1) {
-            // the whole stack and time axis in one persistent launch (lstm_persist_kernel)
-            LstmPersistArgs pa = p->persist[mi].args;
-            for (int l = 0; l < NL; ++l) {
-                Layer& Ly = m->L[l];
-                LstmPersistLayer& s = pa.L[l];
-                s.G = l == 0 ? p->d_G.as<float>() : nullptr;
-                s.bias = Ly.b.as<float>(); s.Wup = l == 0 ? nullptr : Ly.W.as<float>(); s.Wlat = Ly.Wlat.as<float>();
-                s.Hin = l == 0 ? nullptr : Hall + (l - 1) * h_stride;
-                s.H = Hall + l * h_stride; s.Cst = Call + l * c_stride;
-            }
-            pa.n_active = p->d_nact.as<int>(); pa.step_off = p->d_stepoff.as<int>(); pa.cum = p->persist[mi].cum.as<unsigned>();
-            pa.counters = p->d_sync.as<unsigned>(); pa.abort_flag = p->d_sync.as<int>() + 63;
+            // the whole stack and time axis in one persistent launch per chunk of utterance slots (lstm_persist_kernel)
             static const bool want_stamps = env_int("AM_LSTM_STAMPS", 0) != 0;
-            if (want_stamps) {
-                const size_t bytes = sizeof(unsigned long long) * 8 * (size_t)pa.n_groups_total * pa.T;
-                AM_TRY(p->d_stamps.ensure(bytes));
-                HIP_TRY(hipMemsetAsync(p->d_stamps.p, 0, bytes, e->stream));
-                pa.stamps = p->d_stamps.as<unsigned long long>();
-                p->stamps_groups = pa.n_groups_total; p->stamps_T = pa.T;
-            }
-            HIP_TRY(hipMemsetAsync(p->d_sync.p, 0, sizeof(unsigned) * 63, e->stream));   // the abort flag (last word) is cleared once per pass
-            // Overlap of the output layer with the recurrence's tail (single network, logit output): from the step t_A at which at
-            // most 32 utterances are still running, two thirds of the persistent kernel's workgroups have no rows left and
-            // leave.  The output GEMM + log-softmax of the rows of steps < t_A go to the second stream behind a one-wave gate
-            // kernel that returns when the top layer has finished step t_A - 1; they take the CUs as those are vacated.
             static const bool overlap_ok = env_int("AM_LSTM_OVERLAP", 1) != 0;
-            if (overlap_ok && !e->profile && p->members.size() == 1 && p->combine == AM_COMBINE_LOGITS) {
-                int64_t tA = -1;
-                for (int64_t t = 1; t < T; ++t) if (p->n_active[t] <= 32) { tA = t; break; }
-                const int64_t RA = tA > 0 ? p->step_off[tA] / GEMM_BM * GEMM_BM : 0;
-                if (RA >= NP / 4 && RA < rows_pad) { split_rows = RA; split_step = tA; }
+            const size_t n_chunks = p->persist[mi].chunks.size();
+            for (size_t ci = 0; ci < n_chunks; ++ci) {
+                LstmPersistArgs pa = p->persist[mi].chunks[ci];
+                for (int l = 0; l < NL; ++l) {
+                    Layer& Ly = m->L[l];
+                    LstmPersistLayer& s = pa.L[l];
+                    s.G = l == 0 ? p->d_G.as<float>() : nullptr;
+                    s.bias = Ly.b.as<float>(); s.Wup = l == 0 ? nullptr : Ly.W.as<float>(); s.Wlat = Ly.Wlat.as<float>();
+                    s.Hin = l == 0 ? nullptr : Hall + (l - 1) * h_stride;
+                    s.H = Hall + l * h_stride; s.Cst = Call + l * c_stride;
+                }
+                pa.n_active = p->d_nact.as<int>(); pa.step_off = p->d_stepoff.as<int>(); pa.cum = p->persist[mi].cums[ci].as<unsigned>();
+                pa.counters = p->d_sync.as<unsigned>(); pa.abort_flag = p->d_sync.as<int>() + 63;
+                if (want_stamps && ci == 0) {
+                    const size_t bytes = sizeof(unsigned long long) * 8 * (size_t)pa.n_groups_total * pa.T;
+                    AM_TRY(p->d_stamps.ensure(bytes));
+                    HIP_TRY(hipMemsetAsync(p->d_stamps.p, 0, bytes, e->stream));
+                    pa.stamps = p->d_stamps.as<unsigned long long>();
+                    p->stamps_groups = pa.n_groups_total; p->stamps_T = pa.T;
+                }
+                HIP_TRY(hipMemsetAsync(p->d_sync.p, 0, sizeof(unsigned) * 63, e->stream));   // the abort flag (last word) is cleared once per pass
+                // Overlap of the output layer with the recurrence's tail (single network, logit output, one chunk): from the step
+                // t_A at which at most 32 utterances are still running, two thirds of the persistent kernel's workgroups have no
+                // rows left and leave.  The output GEMM + log-softmax of the rows of steps < t_A go to the second stream behind a
+                // one-wave gate kernel that returns when the top layer has finished step t_A - 1; they take the CUs as those are vacated.
+                if (n_chunks == 1 && overlap_ok && !e->profile && p->members.size() == 1 && p->combine == AM_COMBINE_LOGITS) {
+                    int64_t tA = -1;
+                    for (int64_t t = 1; t < T; ++t) if (p->n_active[t] <= 32) { tA = t; break; }
+                    const int64_t RA = tA > 0 ? p->step_off[tA] / GEMM_BM * GEMM_BM : 0;
+                    if (RA >= NP / 4 && RA < rows_pad) { split_rows = RA; split_step = tA; }
+                }
+                if (split_rows > 0) {
+                    if (!p->ev_fork) { HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming)); }
+                    HIP_TRY(hipEventRecord(p->ev_fork, e->stream));            // the counters are zero from here on
+                    HIP_TRY(hipStreamWaitEvent(e->stream2, p->ev_fork, 0));
+                }
+                AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_persist(e->stream, pa); }));
+                if (split_rows > 0) AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_gate(e->stream2, pa, NL - 1, (int)split_step - 1); }, e->stream2));
             }
-            if (split_rows > 0) {
-                if (!p->ev_fork) { HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming)); }
-                HIP_TRY(hipEventRecord(p->ev_fork, e->stream));            // the counters are zero from here on
-                HIP_TRY(hipStreamWaitEvent(e->stream2, p->ev_fork, 0));
-            }
-            AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_persist(e->stream, pa); }));
-            if (split_rows > 0) AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_gate(e->stream2, pa, NL - 1, (int)split_step - 1); }, e->stream2));
             p->used_persist = true;
         } else
         // wavefront over (layer, time): launch d runs layer l at t = d - l; chain length T + NL - 1 instead of T * NL

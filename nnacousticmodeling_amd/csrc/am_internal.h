@@ -135,6 +135,7 @@ struct LstmPersistArgs {
     LstmPersistLayer L[LSTM_MAX_LAYERS];
     int n_layers, U_pad, T;
     int n_groups_total;            // grid = n_groups_total * (U_pad / 16)
+    int slot_base, slot_cap;       // this launch covers the utterance slots [slot_base, slot_base + slot_cap) (longest first: a chunk of a larger file)
     const int* n_active;           // device [T]
     const int* step_off;           // device [T + 1]
     const unsigned* cum;           // device [n_groups_total][T]: arrivals group g has made once its step t is complete
@@ -146,6 +147,7 @@ struct LstmPersistArgs {
 // stack does not fit the persistent form (then the per-step kernels run).  cum_out: [n_groups_total][T] arrival targets.
 bool plan_lstm_persist(LstmPersistArgs& a, int n_slots, const int* n_active_host, unsigned* cum_out /*nullable*/);
 size_t lstm_persist_cum_size(const LstmPersistArgs& a);   // entries of `cum`
+int lstm_persist_capacity(int U_pad, int n_layers);       // utterance slots one launch can take (0: this shape has no persistent form)
 hipError_t launch_lstm_persist(hipStream_t s, const LstmPersistArgs& a);
 hipError_t launch_lstm_gate(hipStream_t s, const LstmPersistArgs& a, int layer, int tcol);   // returns once `layer` has finished step tcol
 

@@ -1396,7 +1396,8 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
     const int l15 = lane & 15, lq = lane >> 4;
     const int U_pad = a.U_pad, ldg = 4 * U_pad;
     const int rows_valid = n_act - row0;                       // > 0
-    const unsigned r_t = (unsigned)(a.step_off[t] + row0);      // packed row of slot row0 at step t
+    const int slot0 = a.slot_base + row0;                       // first utterance slot of this group's rows
+    const unsigned r_t = (unsigned)(a.step_off[t] + slot0);     // its packed row at step t
     persist_stamp(a, gidx, ut, t, 0);
     if (NBU) {   // upward product: needs step t of the layer below (which runs ahead: normally no wait at all)
         if (!persist_wait(a, a.L[li - 1].group0, a.L[li - 1].n_groups, t, s_flag)) return false;
@@ -1420,7 +1421,7 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
     };
     auto fetch_epilogue = [&] {
         if (!NBU) fetch_g();
-        if (live && t > 0) cq = ld_sc1_b128(crs, ((unsigned)(row0 + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u);
+        if (live && t > 0) cq = ld_sc1_b128(crs, ((unsigned)(slot0 + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u);
     };
     auto lat_wait = [&] { return persist_wait(a, Ly.group0, Ly.n_groups, t - 1, s_flag); };   // step t-1 of every group of this layer
     f32x4 acc[NT];
@@ -1436,7 +1437,7 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
         persist_stamp(a, gidx, ut, t, 2);
     }
     f32x4 wnone[1][LSTM_KS] = {};   // stands in for the absent upward weights of a lateral-only pipeline (never read)
-    if (t > 0) ok = persist_products<0, NBL, true, NT>(Ly.H, 0u, Ly.H, (unsigned)(a.step_off[t - 1] + row0), rows_valid, U_pad, wnone, wl, acc, smem, tid, l15, lq, kh, lat_wait, fetch_epilogue) && ok;
+    if (t > 0) ok = persist_products<0, NBL, true, NT>(Ly.H, 0u, Ly.H, (unsigned)(a.step_off[t - 1] + slot0), rows_valid, U_pad, wnone, wl, acc, smem, tid, l15, lq, kh, lat_wait, fetch_epilogue) && ok;
     else if (!NBU) fetch_epilogue();
     if (!ok) return false;
     persist_stamp(a, gidx, ut, t, 4);
@@ -1466,7 +1467,7 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
             cn[u] = c;
             hn[u] = go * am_tanh_rec(c);
         }
-        st_sc1_b128(crs, ((unsigned)(row0 + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u, cn);
+        st_sc1_b128(crs, ((unsigned)(slot0 + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u, cn);
         st_sc1_b128(hrs, ((r_t + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u, hn);
     }
     persist_stamp(a, gidx, ut, t, 5);
@@ -1502,10 +1503,11 @@ __device__ __forceinline__ void persist_body(const LstmPersistArgs& a, const Lst
                 for (int s = 0; s < LSTM_KS; ++s) wu[b][s] = *(const f32x4*)(Ly.Wup + wrow + b * LSTM_KB + 16 * s);
         }
     }
-    int n_next = a.n_active[0];
+    auto local_rows = [&](int n) { n -= a.slot_base; return n < 0 ? 0 : (n > a.slot_cap ? a.slot_cap : n); };   // this launch's share of the active slots
+    int n_next = local_rows(a.n_active[0]);
     for (int t = 0; t < a.T; ++t) {
         const int n_act = n_next;
-        n_next = t + 1 < a.T ? a.n_active[t + 1] : 0;   // requested a whole step ahead: the scalar load's latency is off the chain
+        n_next = t + 1 < a.T ? local_rows(a.n_active[t + 1]) : 0;   // requested a whole step ahead: the scalar load's latency is off the chain
         const int tiles = (n_act + 15) >> 4;
         if (tiles <= 0) break;
         const int q = (tiles + NG - 1) / NG;            // <= NTMAX (host plan)
@@ -1550,6 +1552,20 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_kernel(const LstmPersistA
 }
 
 
+int lstm_persist_capacity(int U_pad, int n_layers)
+{
+    if ((U_pad != 256 && U_pad != 512) || n_layers < 1 || n_layers > LSTM_MAX_LAYERS) return 0;
+    const int nb = U_pad / LSTM_KB, budget = 256 / (U_pad / 16);
+    int tiles = 0;
+    for (int t0 = 1; t0 <= 4096; ++t0) {
+        int total = 0;
+        for (int l = 0; l < n_layers; ++l) { const int ntmax = lstm_persist_ntmax(nb, l > 0); total += (t0 + ntmax - 1) / ntmax; }
+        if (total > budget) break;
+        tiles = t0;
+    }
+    return tiles * 16;
+}
+
 bool plan_lstm_persist(LstmPersistArgs& a, int n_slots, const int* n_active, unsigned* cum_out)
 {
     if (a.n_layers < 1 || a.n_layers > LSTM_MAX_LAYERS || a.T <= 0 || n_slots <= 0) return false;
@@ -1584,7 +1600,9 @@ bool plan_lstm_persist(LstmPersistArgs& a, int n_slots, const int* n_active, uns
                 unsigned* row = cum_out + (size_t)(a.L[l].group0 + g) * a.T;
                 unsigned c = 0;
                 for (int t = 0; t < a.T; ++t) {
-                    const int tiles = (n_active[t] + 15) / 16, q = (tiles + ng[l] - 1) / ng[l];
+                    int na = n_active[t] - a.slot_base;
+                    na = na < 0 ? 0 : (na > a.slot_cap ? a.slot_cap : na);
+                    const int tiles = (na + 15) / 16, q = (tiles + ng[l] - 1) / ng[l];
                     if (tiles > 0 && g * q < tiles) c += (unsigned)tpg;
                     row[t] = c;
                 }
@@ -1635,9 +1653,8 @@ hipError_t launch_lstm_persist(hipStream_t s, const LstmPersistArgs& a)
 
 int lstm_persist_mode()
 {
-    static int mode = -1;   // AM_LSTM_PERSIST=0 keeps the per-step kernels (A/B measurements)
-    if (mode < 0) { const char* v = getenv("AM_LSTM_PERSIST"); mode = v ? atoi(v) : 1; }
-    return mode;
+    const char* v = getenv("AM_LSTM_PERSIST");   // 0 keeps the per-step kernels (A/B measurements, cross-form parity tests); read at every upload
+    return v ? atoi(v) : 1;
 }
 
 constexpr size_t LSTM_THIN_LDS_MAX = 72 * 1024;   // two blocks per CU stay co-resident

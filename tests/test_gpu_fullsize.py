@@ -83,12 +83,12 @@ def test_lstm_config_size(engine, real_ft_path):
         assert np.array_equal(p.lstm_download(), whole)
 
 
-def test_recurrent_forms_agree_bit_for_bit(engine, real_ft_path):
-    """The recurrent stack has two kernel forms: the persistent one (one launch, weights resident in registers; stacks of 256 or
-    512 units with at most 192 utterance slots at 3 layers) and the per-step kernels (everything else).  Both use the same
-    summation order and gate functions, so a frame's posteriors must not depend on the form: a 230-utterance file (per-step
-    kernels) against the same file cut into two halves of 115 utterances (persistent kernel), for 512- and 256-unit stacks,
-    plus the oracle on a sample of utterances."""
+def test_recurrent_forms_agree_bit_for_bit(engine, real_ft_path, monkeypatch):
+    """The recurrent stack has two kernel forms: the persistent one (one launch per chunk of <= 192 utterance slots, weights
+    resident in registers; stacks of 256 or 512 units) and the per-step kernels (every other shape; AM_LSTM_PERSIST=0 forces
+    them).  Both use the same summation order and gate functions, so a frame's posteriors must not depend on the form, on the
+    chunking (230 utterances = two chunks) or on the sharding (two halves of 115), for 512- and 256-unit stacks; plus the
+    oracle on a sample of utterances."""
     ft = orc.centre_frame_transform(orc.load_kaldi_feature_transform(real_ft_path))
     for units, layers, seed in ((512, 3, 7), (256, 2, 8)):
         rng = np.random.default_rng(seed)
@@ -96,11 +96,15 @@ def test_recurrent_forms_agree_bit_for_bit(engine, real_ft_path):
         off = orc.make_offsets(rng, 230, 23000, lo=20, hi=260)
         x = rng.standard_normal((23000, 40)).astype(np.float32)
         p = _pipe(engine, "lstm", layers, params, ft, [0])
-        whole = p.forward_lstm(x, off, timedelay=2)
+        whole = p.forward_lstm(x, off, timedelay=2)                 # persistent form, two chunks of utterance slots
         cut = 115
         a = p.forward_lstm(x[:off[cut]], off[:cut + 1], timedelay=2)
         b = p.forward_lstm(x[off[cut]:], off[cut:] - off[cut], timedelay=2)
         assert np.array_equal(np.concatenate([a, b]), whole)
+        monkeypatch.setenv("AM_LSTM_PERSIST", "0")                  # read at upload: the per-step kernels
+        steps = p.forward_lstm(x, off, timedelay=2)
+        monkeypatch.delenv("AM_LSTM_PERSIST")
+        assert np.array_equal(steps, whole)
         k = 6
         want = orc.predict(orc.LSTM(params, layers), x[:off[k]], off[:k + 1], True, 1, 2, ft)
         assert np.max(np.abs(whole[:off[k]] - want)) <= TOL

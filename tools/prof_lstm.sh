@@ -15,5 +15,6 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > $OUT/pm
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_tcc -- $B > $OUT/pmc_tcc.log 2>&1 || { echo pmc_tcc failed; tail -5 $OUT/pmc_tcc.log; }
 f=$(find $OUT/trace -name "*_kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats.csv
 for d in pmc_sq pmc_fetch pmc_write pmc_tcc; do python3 tools/pmc_by_kernel.py $OUT/$d > $OUT/$d.txt 2>&1; done
+rm -rf $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_tcc   # the per-dispatch tables are large; the per-kernel averages are what is kept
 rm -rf $OUT/trace
 grep -h "persist\|wreg\|thin" $OUT/pmc_*.txt | cut -c1-400
