@@ -210,10 +210,12 @@ def secondary_records(eng, ft, params, layers, x, steps):
     p.ff_upload(x[:n57], None, n57, 0, 0)
     wall, _, prof = timed_runs(eng, p.ff_run, max(steps, 5), 2)
     k = max(steps, 5)
-    _, _, ach = gemm_roofline(prof, FLOPS_PER_FRAME["4x1024"] * n57 * k)
+    whole = FLOPS_PER_FRAME["4x1024"] * n57 * k / wall / 1e12
     out["n57919"] = {"value": n57 * k / wall, "unit": "frames/s", "ms_per_step": wall * 1e3 / k, "frames": n57,
-                     "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS if ach else None},
-                     "frac_of_mfma_ceiling_whole_step": FLOPS_PER_FRAME["4x1024"] * n57 * k / wall / 1e12 / PEAK_F32_MFMA_TFLOPS}
+                     "roofline": {"bound": "mfma", "kernel": "whole step (at this size the rows go down the layers as two chains on two streams, so the GEMM launches overlap "
+                                  "and their summed durations exceed the wall time: the fraction is flop / wall time / peak)",
+                                  "achieved": whole, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": whole / PEAK_F32_MFMA_TFLOPS},
+                     "gemm_launch_ms_sum_per_step": sum(prof[k_][1] for k_ in ("gemm_hidden", "gemm_out") if k_ in prof) / k}
     p.close()
     m4.close()
     # (iii) BASELINE configs[2]: 6x2048 on 440 spliced + 100 i-vector columns

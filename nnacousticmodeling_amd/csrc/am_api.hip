@@ -69,7 +69,8 @@ struct DevBuf {
 struct am_engine {
     int device = -1;
     hipStream_t stream = nullptr;    // compute stream: every GEMM / frontend / recurrent kernel
-    hipStream_t stream2 = nullptr;   // copy stream: D2H of chunk c overlaps the compute of chunk c+1 (am_forward_ff)
+    hipStream_t stream2 = nullptr;   // copy stream: D2H of chunk c overlaps the compute of chunk c+1 (am_forward_ff); second row chain
+    hipStream_t chain[2] = {nullptr, nullptr};   // third / fourth row chain of a feed-forward chunk (ff_run_chunks)
     hipEvent_t s2_tail = nullptr;    // last work enqueued on stream2
     bool s2_dirty = false;
     int precision = AM_PRECISION_F32;  // AM_PRECISION_* for the feed-forward Linear layers
@@ -161,7 +162,8 @@ struct am_pipeline {
     DevBuf d_stamps;                    // AM_LSTM_STAMPS=1: timeline of the last member's persistent launch (am_lstm_stamps)
     int stamps_groups = 0, stamps_T = 0;
     bool used_persist = false;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // second-stream overlap of the output layer with the recurrence's tail
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // second-stream overlap of the output layer with the recurrence's tail; row chains
+    hipEvent_t ev_chain[2] = {nullptr, nullptr};
     // the recurrent launch sequence (thousands of ~2 us kernels) is replayed from a hipGraph from the 2nd run on
     int lstm_runs = 0;
     hipGraph_t graph = nullptr;
@@ -243,6 +245,7 @@ static int sync_all(am_engine* e)
 {
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream2));
+    for (auto c : e->chain) HIP_TRY(hipStreamSynchronize(c));
     e->s2_dirty = false;
     return AM_OK;
 }
@@ -299,6 +302,7 @@ extern "C" int am_engine_create(int device, am_engine** out)
     snprintf(e->name, sizeof(e->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->chain[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&e->chain[1], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->s2_tail, hipEventDisableTiming) != hipSuccess) { delete e; return fail(AM_EHIP, "hipStreamCreate failed"); }
     hipError_t r = init_kernels();
     if (r != hipSuccess) { (void)hipStreamDestroy(e->stream); delete e; return fail(AM_EHIP, "kernel init failed: %s", hipGetErrorString(r)); }
@@ -329,6 +333,7 @@ static void engine_teardown(am_engine* e)
     (void)hipStreamSynchronize(e->stream2);
     (void)hipEventDestroy(e->s2_tail);
     (void)hipStreamDestroy(e->stream2);
+    for (auto c : e->chain) if (c) { (void)hipStreamSynchronize(c); (void)hipStreamDestroy(c); }
     for (auto& r : e->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -718,6 +723,7 @@ extern "C" int am_pipeline_destroy(am_pipeline* p)
     for (auto ev : p->chunk_done) (void)hipEventDestroy(ev);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+    for (auto ev : p->ev_chain) if (ev) (void)hipEventDestroy(ev);
     p->drop_graph();
     for (DevBuf* d : {&p->d_shifts, &p->d_add, &p->d_scale, &p->d_rplw, &p->d_rplb, &p->d_rpllb, &p->d_prior, &p->d_x, &p->d_ivec, &p->d_in, &p->d_in_s,
                       &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c, &p->d_nact, &p->d_stepoff, &p->d_sync, &p->d_stamps})
@@ -843,15 +849,16 @@ static float final_divisor(const am_pipeline* p)
     return n > 1 ? (float)n : 0.f;
 }
 
-static int member_finish(am_pipeline* p, int mi, int64_t rows)
+static int member_finish(am_pipeline* p, int mi, int64_t rows, int64_t row0 = 0, hipStream_t on = nullptr)
 {
-    // log-posterior averaging: normalise this member and add it to the running sum (predict_folds.py:207-212)
+    // log-posterior averaging: normalise this member and add it to the running sum (predict_folds.py:207-212); rows [row0, row0 + rows)
     am_model* m0 = p->members[0];
     FinishArgs f{};
-    f.in = p->d_acc.as<float>(); f.ldin = p->acc_ld;
-    f.out = p->d_acc2.as<float>(); f.ldout = p->acc_ld;
+    f.in = p->d_acc.as<float>() + row0 * p->acc_ld; f.ldin = p->acc_ld;
+    f.out = p->d_acc2.as<float>() + row0 * p->acc_ld; f.ldout = p->acc_ld;
     f.n = rows; f.C = m0->C; f.normalise = 1; f.accumulate = mi > 0;
-    return run_kernel(p->e, K_FINISH, [&] { return launch_finish(p->e->stream, f); });
+    hipStream_t st = on ? on : p->e->stream;
+    return run_kernel(p->e, K_FINISH, [&] { return launch_finish(st, f); }, st);
 }
 
 static int final_finish(am_pipeline* p, int64_t rows, float* out, const int* row_map, int64_t row0 = 0, hipStream_t on = nullptr)
@@ -1011,11 +1018,14 @@ extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, i
     return AM_OK;
 }
 
-static int ff_member_forward(am_pipeline* p, int mi, int64_t rows_pad, float* acc)
+static int ff_member_forward(am_pipeline* p, int mi, int64_t rows_pad, float* acc, int64_t row0 = 0, hipStream_t on = nullptr)
 {
+    // rows [row0, row0 + rows_pad) of the chunk (row0 a multiple of the GEMM's row tile), on stream `on` (default: the compute stream)
     am_engine* e = p->e;
     am_model* m = p->members[mi];
-    const float* A = p->d_in.as<float>();
+    hipStream_t st = on ? on : e->stream;
+    const float* A = p->d_in.as<float>() + row0 * m->in_pad;
+    acc += row0 * m->C_pad;
     int lda = m->in_pad;
     for (int l = 0; l <= m->n_layers; ++l) {
         Layer& Ly = m->L[l];
@@ -1024,13 +1034,13 @@ static int ff_member_forward(am_pipeline* p, int mi, int64_t rows_pad, float* ac
         g.M_pad = (int)rows_pad; g.N_pad = Ly.out_pad; g.K_pad = Ly.in_pad; g.act = m->act;
         int id;
         if (l < m->n_layers) {
-            g.C = ((l & 1) ? p->d_act1 : p->d_act0).as<float>(); g.ldc = Ly.out_pad; g.epi = EPI_ACT; g.alpha = 1.f;
+            g.C = ((l & 1) ? p->d_act1 : p->d_act0).as<float>() + row0 * Ly.out_pad; g.ldc = Ly.out_pad; g.epi = EPI_ACT; g.alpha = 1.f;
             id = K_GEMM_HIDDEN;
         } else {
             g.C = acc; g.ldc = m->C_pad; g.epi = epilogue_mode(p, mi, &g.alpha);
             id = K_GEMM_OUT;
         }
-        AM_TRY(run_kernel(e, id, [&] { return launch_gemm(e->stream, g); }));
+        AM_TRY(run_kernel(e, id, [&] { return launch_gemm(st, g); }, st));
         A = g.C; lda = g.ldc;
     }
     return AM_OK;
@@ -1131,6 +1141,37 @@ static int ff_run_chunks(am_pipeline* p, int64_t chunk_rows, float* host_y)
         }
         if (m0->tdnn) AM_TRY(run_kernel(e, K_SPLICE_FT, [&] { return launch_splice_tdnn(e->stream, s, m0->win, m0->in_pad, nc_pad); }));
         else AM_TRY(run_kernel(e, K_SPLICE_FT, [&] { return launch_splice_ft(e->stream, s); }));
+        // Tile quantisation: a layer of (rows / 256) x (width / 256) tiles on 256 CUs runs in whole rounds (57,919 rows x 1024:
+        // 908 tiles = 3.55 rounds, run as 4).  When the last round is mostly empty the chunk's rows are cut into two ranges (AM_FF_CHAINS, up to four; two measured best) that
+        // go down the layers on as many streams: rows are independent (same bits), and the other chains' tiles fill the CUs the
+        // first chain's partial rounds leave idle.  (AM_FF_CHAINS=1 switches it off.)
+        int n_chains = 1;
+        static const int64_t max_chains = std::min<int64_t>(4, std::max<int64_t>(1, env_int("AM_FF_CHAINS", 2)));
+        if (max_chains > 1 && !host_y && !split && !m0->tdnn && nc_pad >= 16 * GEMM_BM) {
+            const double rounds = (double)(nc_pad / GEMM_BM) * std::max(1, m0->max_width / 256) / 256.0;
+            if (std::ceil(rounds) / rounds > 1.04) n_chains = (int)max_chains;
+        }
+        if (n_chains > 1) {
+            if (!p->ev_fork) { HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming)); }
+            for (auto& ev : p->ev_chain) if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            hipStream_t streams[4] = {e->stream, e->stream2, e->chain[0], e->chain[1]};
+            hipEvent_t joins[4] = {nullptr, p->ev_join, p->ev_chain[0], p->ev_chain[1]};
+            HIP_TRY(hipEventRecord(p->ev_fork, e->stream));
+            const int64_t tiles_m = nc_pad / GEMM_BM;
+            for (int br = 0; br < n_chains; ++br) {
+                hipStream_t st = streams[br];
+                const int64_t t0 = tiles_m * br / n_chains, t1 = tiles_m * (br + 1) / n_chains;
+                const int64_t r0 = t0 * GEMM_BM, rp = (t1 - t0) * GEMM_BM, nr = std::max<int64_t>(0, std::min(nc, r0 + rp) - r0);
+                if (br > 0) HIP_TRY(hipStreamWaitEvent(st, p->ev_fork, 0));
+                for (int mi = 0; mi < (int)p->members.size(); ++mi) {
+                    AM_TRY(ff_member_forward(p, mi, rp, p->d_acc.as<float>(), r0, st));
+                    if (p->combine == AM_COMBINE_LOGPOST && nr > 0) AM_TRY(member_finish(p, mi, nr, r0, st));
+                }
+                if (nr > 0) AM_TRY(final_finish(p, nr, p->d_out.as<float>() + (c0 + r0) * m0->C, nullptr, r0, st));
+                if (br > 0) HIP_TRY(hipEventRecord(joins[br], st));
+            }
+            for (int br = 1; br < n_chains; ++br) HIP_TRY(hipStreamWaitEvent(e->stream, joins[br], 0));
+        } else {
         for (int mi = 0; mi < (int)p->members.size(); ++mi) {
             if (m0->tdnn && split) AM_TRY(tdnn_member_forward_split(p, mi, nc_pad, p->d_acc.as<float>()));
             else if (m0->tdnn) AM_TRY(tdnn_member_forward(p, mi, nc_pad, p->d_acc.as<float>()));
@@ -1139,6 +1180,7 @@ static int ff_run_chunks(am_pipeline* p, int64_t chunk_rows, float* host_y)
             if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(member_finish(p, mi, nc));
         }
         AM_TRY(final_finish(p, nc, p->d_out.as<float>() + c0 * m0->C, nullptr));
+        }
         if (host_y) {
             if (p->chunk_done.size() <= n_chunks) {
                 hipEvent_t ev;
