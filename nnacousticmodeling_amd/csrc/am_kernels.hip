@@ -502,7 +502,29 @@ __global__ __launch_bounds__(256) void splice_ft_kernel(
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { av[e] = (kind == 0 && has_ft) ? add[col + e] : 0.0f; sv[e] = (kind == 0 && has_ft) ? scale[col + e] : 1.0f; }
 
-        for (int rr = rsub; rr < rows_per_block; rr += rows_per_pass) {
+        // the common case first: the spliced feature columns of a block of real rows, four rows' loads in flight per lane before
+        // the first store (one row at a time left the kernel at 3.6 TB/s, latency-bound: MI355X_MICROARCH.md, keep >= 4 loads per lane)
+        int rr0 = rsub;
+        if (!HALVES && VEC == 4 && kind == 0 && rblock + rows_per_block <= n) {
+            for (; rr0 + 3 * rows_per_pass < rows_per_block; rr0 += 4 * rows_per_pass) {
+                f32x4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    long long src = first + rblock + rr0 + u * rows_per_pass + shift;
+                    src = src < 0 ? 0 : (src > ext_rows - 1 ? ext_rows - 1 : src);
+                    t[u] = *(const f32x4*)(x + src * D + d);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (has_ft) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float s1 = t[u][e] + av[e]; t[u][e] = s1 * sv[e]; }
+                    }
+                    *(f32x4*)(out + (rblock + rr0 + u * rows_per_pass) * ldo + col) = t[u];
+                }
+            }
+        }
+        for (int rr = rr0; rr < rows_per_block; rr += rows_per_pass) {
             const long long r = rblock + rr;
             if (r >= n_pad) break;
             float v[VEC];
