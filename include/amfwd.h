@@ -184,8 +184,8 @@ int am_forward_ff(am_pipeline* p, const float* x, const float* ivec, int64_t n, 
  * am_lstm_run is asynchronous.  LSTM stacks of 256 or 512 units whose row groups fit the chip (<= 192 utterances at three
  * 512-unit layers) run as ONE persistent launch with the weights resident in registers (lstm_persist_kernel); every other
  * shape, and the GRU / MGRU / peephole cells, run one launch per time step of the (layer, time) wavefront.  Both forms give
- * the same bits.  The persistent kernel's inter-workgroup waits are bounded (2 s): if one ever times out the pass is marked
- * invalid and am_lstm_download / am_decode_pipeline return AM_EHIP instead of hanging the GPU.
+ * the same bits.  The persistent kernel's inter-workgroup waits are bounded (2 s): if one ever times out, every workgroup leaves and
+ * am_lstm_download / am_decode_pipeline repeat the pass on the per-step kernels (a line on stderr says so) -- never a hung GPU.
  * Environment switches (measurement only): AM_LSTM_PERSIST=0 per-step kernels only; AM_LSTM_OVERLAP=0 no second-stream
  * overlap of the output layer with the recurrence's tail; AM_LSTM_GRAPH=0|1 hipGraph replay of the per-step form. */
 int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec, const int64_t* offsets, int n_utts, int timedelay);

@@ -1238,7 +1238,7 @@ __global__ __launch_bounds__(512) void lstm_thin_kernel(const LstmWavefrontArgs 
 // reports an error instead of hanging the GPU.
 // ---------------------------------------------------------------------------------------------------
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr int LSTM_P_TIMEOUT = 200000000;   // ticks of s_memrealtime (100 MHz)
+constexpr int LSTM_P_TIMEOUT = 200000000;   // ticks of s_memrealtime (100 MHz): 2 s
 
 __device__ __forceinline__ unsigned ld_agent_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ f32x4 ld_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off)

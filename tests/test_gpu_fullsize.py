@@ -111,6 +111,30 @@ def test_recurrent_forms_agree_bit_for_bit(engine, real_ft_path, monkeypatch):
         p.close()
 
 
+def test_persistent_kernel_gives_up_and_falls_back(engine, real_ft_path, monkeypatch, capfd):
+    """The persistent recurrent kernel's inter-workgroup waits are bounded (2 s).  With an arrival target nobody can reach
+    (AM_LSTM_TEST_TIMEOUT=1 inflates one group's table at upload) the waits must time out, every workgroup must leave, and the
+    download must come back with the per-step kernels' result -- the same bits as an undisturbed pass -- instead of hanging."""
+    import time
+    ft = orc.centre_frame_transform(orc.load_kaldi_feature_transform(real_ft_path))
+    rng = np.random.default_rng(21)
+    params = orc.make_lstm_params(rng, 40, 256, 2, 1909)
+    off = orc.make_offsets(rng, 24, 2400, lo=20, hi=200)
+    x = rng.standard_normal((2400, 40)).astype(np.float32)
+    p = _pipe(engine, "lstm", 2, params, ft, [0])
+    good = p.forward_lstm(x, off)
+    monkeypatch.setenv("AM_LSTM_TEST_TIMEOUT", "1")
+    t0 = time.perf_counter()
+    got = p.forward_lstm(x, off)
+    dt = time.perf_counter() - t0
+    monkeypatch.delenv("AM_LSTM_TEST_TIMEOUT")
+    assert np.array_equal(got, good)
+    assert 1.5 < dt < 30.0                       # it waited for its bound, then recovered
+    assert "repeating the pass on the per-step kernels" in capfd.readouterr().err
+    assert np.array_equal(p.forward_lstm(x, off), good)   # and the next upload is back on the persistent kernel
+    p.close()
+
+
 def test_edge_cases(engine, real_ft_path):
     rng = np.random.default_rng(5)
     ft = orc.load_kaldi_feature_transform(real_ft_path)
