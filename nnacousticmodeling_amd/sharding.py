@@ -128,6 +128,8 @@ class PosteriorRunner:
         self.shards = _normalise_shards(devices)
         self.devices = [g for g, _ in self.shards]
         self._state = {}
+        self._pinned = {}            # (n, c) -> page-locked blocks handed out by _out
+        self._requests = {}          # (n, c) -> how often that shape has been asked for
         self._lock = threading.Lock()
 
     def _dev(self, shard):
@@ -141,14 +143,30 @@ class PosteriorRunner:
                     st.engine.set_precision(self.precision)
             return st
 
-    def _out(self, n, c, zero=False):
+    def _out(self, n, c):
         """The gathered [N, C] array.  Page-locked when the backend offers it (am_host_alloc): every shard's download then
-        runs at PCIe rate straight into its slice, instead of being staged through the driver's bounce buffers."""
+        runs at PCIe rate straight into its slice, instead of being staged through the driver's bounce buffers.
+        Page-locking 442 MB costs ~0.1 s, more than a warm pass over a core-test-sized file, so the blocks are pooled: a block
+        is handed out again once nothing but the pool refers to it (the caller has dropped the array and every view of it)."""
         alloc = getattr(self.backend, "pinned_empty", None)
-        y = alloc((n, c), np.float32) if (alloc is not None and n * c > 0) else np.empty((n, c), dtype=np.float32)
-        if zero:
-            y[...] = 0.0
-        return y
+        if alloc is None or n * c == 0:
+            return np.empty((n, c), dtype=np.float32)
+        import sys
+        with self._lock:
+            seen = self._requests[(n, c)] = self._requests.get((n, c), 0) + 1
+            if len(self.shards) == 1 and seen == 1:
+                # one shard, first request of this shape: a one-shot call is faster into pageable memory (43 ms for the
+                # core-test file) than into memory it first has to page-lock (~100 ms); a repeated workload gets the pool
+                return np.empty((n, c), dtype=np.float32)
+            pool = self._pinned.setdefault((n, c), [])
+            for y in pool:
+                if sys.getrefcount(y) <= 3:      # the pool's list, the loop variable, getrefcount's argument
+                    return y
+            y = alloc((n, c), np.float32)
+            pool.append(y)
+            if len(pool) > 4:                    # callers that keep many results alive: stop pooling the oldest
+                pool.pop(0)
+            return y
 
     def _configure(self, st, ensemble, D, shifts, ft, d_iv, prior, combine, normalise):
         specs = list(ensemble.members())
@@ -220,7 +238,7 @@ class PosteriorRunner:
         n, D = x.shape
         iv = None if ivectors is None else np.ascontiguousarray(ivectors, dtype=np.float32)
         d_iv = 0 if iv is None else iv.shape[1]
-        y = self._out(n, ens.num_classes, zero=True)
+        y = self._out(n, ens.num_classes)   # every row belongs to an utterance of some bin: all of it is overwritten
         bins = lstm_bins(offsets, len(self.shards))
         jobs = []
         for utts, shard in zip(bins, self.shards):
@@ -269,6 +287,7 @@ class PosteriorRunner:
                 m.close()
             st.engine.close()
         self._state = {}
+        self._pinned = {}
 
 
 _default_runners = {}
