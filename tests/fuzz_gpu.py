@@ -81,7 +81,7 @@ def one(eng, rng, ft_full, it):
     desc = {"it": it, "kind": kind, "D": D, "C": C, "prior": prior is not None}
     p = Pipeline(eng)
     if kind in ("ff", "tdnn"):
-        n = int(rng.choice([1, 2, 63, 255, 256, 257, 1000, 3001]))
+        n = int(rng.choice([1, 2, 63, 255, 256, 257, 1000, 3001, 6007]))   # 6007: above the 4096 padded rows from which a chunk may run as two row chains
         x = rng.standard_normal((n, D)).astype(np.float32)
         if kind == "ff":
             s = int(rng.choice([0, 1, 5]))
