@@ -36,8 +36,8 @@ def main():
     st = st.astype(np.int64)
     lens = np.diff(off)
     nact = np.array([(lens > t).sum() for t in range(T.value)])
-    # stamp slots -- first form: 0 start, 1 upward wait done, 2 upward product done, 3 lateral wait done, 4 lateral product done,
-    # 5 stores issued, 6 published; split form: 0 start, 1 wait done, 2 product done, 3 gate exchange done, 5 stores issued, 6 published
+    # stamp slots: 0 step start, 1 upward wait done, 2 upward product done, 4 lateral wait + product done, 5 stores issued, 6 published
+    # (layer 0 has no upward product: 0, 1, 4, 5, 6)
     print("groups", ng.value, "steps", T.value, "span of the launch: %.1f us" % ((st[st > 0].max() - st[st > 0].min()) / 100.0))
     for g in range(ng.value):
         s = st[g]
