@@ -1638,7 +1638,7 @@ size_t lstm_persist_cum_size(const LstmPersistArgs& a) { return (size_t)a.n_grou
 // One wave that returns once the `n` groups first.. have reached their step-`tcol` arrival targets (bounded like every other wait).
 // Launched on a second stream in front of the output layer's GEMM for the rows of steps <= tcol: as the persistent kernel's
 // workgroups run out of rows and leave, that GEMM takes over their CUs while the few remaining utterances are still stepping.
-__global__ __launch_bounds__(64) void lstm_gate_kernel(const unsigned* counters, const unsigned* cum, int T, int first, int n, int tcol, int* abort_flag)
+__global__ __launch_bounds__(64) void lstm_gate_kernel(const unsigned* counters, const unsigned* cum, int T, int first, int n, int tcol, int* abort_flag, unsigned long long timeout)
 {
     const int lane = threadIdx.x;
     if (lane >= n) return;
@@ -1649,7 +1649,7 @@ __global__ __launch_bounds__(64) void lstm_gate_kernel(const unsigned* counters,
     while (ld_agent_u32(c) < target) {
         __builtin_amdgcn_s_sleep(8);
         if ((++it & 63) == 0 && (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-                                __builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)LSTM_P_TIMEOUT)) {
+                                __builtin_amdgcn_s_memrealtime() - t0 > timeout)) {
             __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
@@ -1659,7 +1659,9 @@ __global__ __launch_bounds__(64) void lstm_gate_kernel(const unsigned* counters,
 hipError_t launch_lstm_gate(hipStream_t s, const LstmPersistArgs& a, int layer, int tcol)
 {
     if (layer < 0 || layer >= a.n_layers || tcol < 0 || tcol >= a.T) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(lstm_gate_kernel, dim3(1), dim3(64), 0, s, a.counters, a.cum, a.T, a.L[layer].group0, a.L[layer].n_groups, tcol, a.abort_flag);
+    // unlike the in-kernel waits (one step's worth of somebody else's work) this one legitimately lasts most of the pass: 2 s + 100 us per step
+    const unsigned long long timeout = (unsigned long long)LSTM_P_TIMEOUT + (unsigned long long)a.T * 10000ull;
+    hipLaunchKernelGGL(lstm_gate_kernel, dim3(1), dim3(64), 0, s, a.counters, a.cum, a.T, a.L[layer].group0, a.L[layer].n_groups, tcol, a.abort_flag, timeout);
     return hipGetLastError();
 }
 
