@@ -4,6 +4,7 @@
 #include "am_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1384,6 +1385,8 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
 }
 
 static int lstm_enqueue(am_pipeline* p);
+static std::atomic<int> g_lstm_fallbacks{0};
+extern "C" int am_lstm_fallback_count(void) { return g_lstm_fallbacks.load(); }
 
 // After a synchronisation: did the persistent recurrent kernel give up on a wait (lstm_persist_kernel's abort flag)?
 static int persist_check(am_pipeline* p)
@@ -1396,6 +1399,7 @@ static int persist_check(am_pipeline* p)
         // hand-off was lost).  Every workgroup has left; the pass is invalid.  Repeat it once on the per-step kernels (same
         // bits), keep this upload on them, and say so: never a wrong result, never a hung GPU.
         fprintf(stderr, "libamfwd: the persistent recurrent kernel gave up on an inter-workgroup wait; repeating the pass on the per-step kernels\n");
+        ++g_lstm_fallbacks;
         for (auto& pl : p->persist) pl.release();
         p->drop_graph();
         p->results_valid = true;

@@ -184,7 +184,11 @@ def main():
         if err > worst[0]:
             worst = (err, desc)
         it += 1
-    print("iterations", it, "failures", fails, "worst", worst, flush=True)
+    from nnacousticmodeling_amd import _lib
+    fallbacks = _lib.load().am_lstm_fallback_count()   # persistent recurrent launches that timed out and were repeated (must be 0)
+    print("iterations", it, "failures", fails, "worst", worst, "recurrent fallbacks", fallbacks, flush=True)
+    if fallbacks:
+        sys.exit(2)
     sys.exit(1 if fails else 0)
 
 

@@ -111,6 +111,7 @@ def test_recurrent_forms_agree_bit_for_bit(engine, real_ft_path, monkeypatch):
         p.close()
 
 
+@pytest.mark.expects_fallback
 def test_persistent_kernel_gives_up_and_falls_back(engine, real_ft_path, monkeypatch, capfd):
     """The persistent recurrent kernel's inter-workgroup waits are bounded (2 s).  With an arrival target nobody can reach
     (AM_LSTM_TEST_TIMEOUT=1 inflates one group's table at upload) the waits must time out, every workgroup must leave, and the
