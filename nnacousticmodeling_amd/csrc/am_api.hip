@@ -140,6 +140,11 @@ struct am_pipeline {
     int halo_lo = 0, halo_hi = 0;
     bool has_ivec = false;
     DevBuf d_x, d_ivec, d_in, d_in_s, d_act0, d_act1, d_acc, d_acc2, d_out;
+    // the Linear stack as one work-queue launch (gemm_stack_kernel): one activation plane per hidden layer + its counters
+    DevBuf d_stack, d_ffsync;          // float [planes][stack_rows * stack_width]; unsigned {abort flag, queue, done[hidden][row tiles]}
+    int64_t stack_rows = 0; int stack_width = 0, stack_planes = 0;
+    bool used_stack = false;           // the current results came from gemm_stack_kernel (its abort flag is checked before they are handed out)
+    bool stack_off = false;            // a stack launch gave up on a wait: this pipeline stays on the per-layer launches
     int acc_ld = 0;        // leading dimension of d_acc / d_acc2 in the current run (C_pad, or C padded to 256 in split mode)
     bool ran_split = false;
     bool fell_back = false;  // the last split-f16 run overflowed f16 and was repeated on the exact path
@@ -282,7 +287,7 @@ extern "C" const char* am_version(void) { return "amfwd 0.1 (gfx950)"; }
 
 extern "C" const char* am_kernel_name(int id)
 {
-    static const char* names[K_COUNT] = {"splice_ft", "gemm_hidden", "gemm_out", "finish", "gather_ft", "lstm_upward", "lstm_step", "viterbi", "split_convert", "gemm_split"};
+    static const char* names[K_COUNT] = {"splice_ft", "gemm_hidden", "gemm_out", "finish", "gather_ft", "lstm_upward", "lstm_step", "viterbi", "split_convert", "gemm_split", "gemm_stack"};
     return (id >= 0 && id < K_COUNT) ? names[id] : nullptr;
 }
 
@@ -727,7 +732,7 @@ extern "C" int am_pipeline_destroy(am_pipeline* p)
     for (auto ev : p->ev_chain) if (ev) (void)hipEventDestroy(ev);
     p->drop_graph();
     for (DevBuf* d : {&p->d_shifts, &p->d_add, &p->d_scale, &p->d_rplw, &p->d_rplb, &p->d_rpllb, &p->d_prior, &p->d_x, &p->d_ivec, &p->d_in, &p->d_in_s,
-                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c, &p->d_nact, &p->d_stepoff, &p->d_sync, &p->d_stamps})
+                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_stack, &p->d_ffsync, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c, &p->d_nact, &p->d_stepoff, &p->d_sync, &p->d_stamps})
         d->release();
     for (auto& pl : p->persist) pl.release();
     am_engine* e = p->e;
@@ -961,6 +966,20 @@ static int tdnn_member_forward_split(am_pipeline* p, int mi, int64_t frames, flo
     return AM_OK;
 }
 
+static std::atomic<int> g_lstm_fallbacks{0};   // passes a persistent kernel (recurrent, or the Linear stack) gave up on and the per-launch kernels repeated (am_lstm_fallback_count)
+
+// The whole Linear stack of a member as ONE work-queue launch (gemm_stack_kernel) instead of one launch per layer: AM_FF_STACK = 0 off,
+// 1 for resident passes of at least 16 row tiles, 2 whatever the size (off by default while it is slower than the row chains).
+static int ff_stack_mode() { return (int)env_int("AM_FF_STACK", 0); }   // read on every call: the tests switch it
+static int64_t ff_stack_min_rows() { return ff_stack_mode() >= 2 ? GEMM_BM : 16 * GEMM_BM; }
+static bool ff_stack_shape_ok(const am_model* m)
+{
+    if (m->tdnn || m->n_layers < 1 || m->n_layers > GEMM_STACK_MAX_HIDDEN) return false;
+    for (int l = 0; l < m->n_layers; ++l) if (m->L[l].out_pad % 256 || m->L[l].in_pad % 32) return false;
+    const Layer& out = m->L[m->n_layers];
+    return out.out_pad % 256 == 0 || out.out_pad % 384 == 0;
+}
+
 extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, int64_t n, int halo_lo, int halo_hi)
 {
     AM_TRY(check_ready(p, AM_NET_FF));
@@ -1007,6 +1026,14 @@ extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, i
         AM_TRY(p->d_act0.ensure(sizeof(float) * rows * width));
         AM_TRY(p->d_act1.ensure(sizeof(float) * rows * width));
     }
+    // one plane per hidden layer for the single-launch form of the stack (a plane re-written inside a launch could be read stale)
+    int planes = 0;
+    for (auto* m : p->members) if (ff_stack_shape_ok(m)) planes = std::max(planes, m->n_layers);
+    if (planes > 0 && ff_stack_mode() > 0 && rows >= ff_stack_min_rows()) {
+        AM_TRY(p->d_stack.ensure(sizeof(float) * (size_t)planes * rows * width));
+        AM_TRY(p->d_ffsync.ensure(sizeof(unsigned) * (2 + (size_t)planes * (rows / GEMM_BM))));
+        p->stack_rows = rows; p->stack_width = width; p->stack_planes = planes;
+    } else p->stack_planes = 0;
     }
     const int acc_w = std::max<int>(m0->C_pad, (int)round_up(m0->C, 256));
     AM_TRY(p->d_acc.ensure(sizeof(float) * rows * acc_w));
@@ -1016,6 +1043,40 @@ extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, i
     AM_TRY(sync_all(e));
     p->n = n; p->halo_lo = halo_lo; p->halo_hi = halo_hi; p->has_ivec = ivec != nullptr;
     p->mode = 1; p->results_valid = false;
+    return AM_OK;
+}
+
+static int ff_member_forward_stack(am_pipeline* p, int mi, int64_t rows_pad, float* acc)
+{
+    am_engine* e = p->e;
+    am_model* m = p->members[mi];
+    GemmStackArgs a{};
+    const int tiles_m = (int)(rows_pad / GEMM_BM);
+    const size_t plane = (size_t)p->stack_rows * p->stack_width;
+    int item = 0;
+    for (int l = 0; l <= m->n_layers; ++l) {
+        Layer& Ly = m->L[l];
+        GemmStackLayer& S = a.L[l];
+        S.W = Ly.W.as<float>(); S.bias = Ly.b.as<float>(); S.ldw = Ly.in_pad;
+        if (l < m->n_layers) {
+            S.C = p->d_stack.as<float>() + (size_t)l * plane; S.ldc = Ly.out_pad; S.tiles_n = Ly.out_pad / 256; S.nk = Ly.in_pad / 32;
+        } else {
+            const bool wide = Ly.out_pad % 256 != 0;
+            S.C = acc; S.ldc = m->C_pad; S.tiles_n = Ly.out_pad / (wide ? 384 : 256); S.nk = Ly.in_pad / (wide ? 16 : 32);
+        }
+        S.item0 = item;
+        item += tiles_m * S.tiles_n;
+    }
+    a.A0 = p->d_in.as<float>(); a.lda0 = m->in_pad;
+    a.n_hidden = m->n_layers; a.tiles_m = tiles_m; a.act = m->act;
+    a.out_epi = epilogue_mode(p, mi, &a.out_alpha);
+    unsigned* sync = p->d_ffsync.as<unsigned>();
+    a.abort_flag = (int*)sync; a.queue = (int*)sync + 1; a.done = sync + 2; a.n_items = item;
+    a.test_extra = env_int("AM_FF_TEST_TIMEOUT", 0) ? 1 : 0;   // test hook: arrival targets nobody reaches -> the waits must time out
+    HIP_TRY(hipMemsetAsync(sync + 1, 0, sizeof(unsigned) * (1 + (size_t)m->n_layers * tiles_m), e->stream));
+    const int out_pad = m->L[m->n_layers].out_pad;
+    AM_TRY(run_kernel(e, K_GEMM_STACK, [&] { return launch_gemm_stack(e->stream, a, out_pad); }));
+    p->used_stack = true;
     return AM_OK;
 }
 
@@ -1128,6 +1189,10 @@ static int ff_run_chunks(am_pipeline* p, int64_t chunk_rows, float* host_y)
         HIP_TRY(hipMemsetAsync(e->d_overflow.p, 0, sizeof(int), e->stream));
     }
     if (m0->tdnn) chunk_rows = std::min<int64_t>(chunk_rows, tdnn_chunk_frames(m0));
+    p->used_stack = false;
+    bool stack_ok = !host_y && !split && !p->stack_off && p->stack_planes > 0 && ff_stack_mode() > 0;
+    for (auto* m : p->members) stack_ok = stack_ok && ff_stack_shape_ok(m) && m->n_layers <= p->stack_planes && m->max_width <= p->stack_width;
+    if (stack_ok) HIP_TRY(hipMemsetAsync(p->d_ffsync.p, 0, sizeof(unsigned), e->stream));   // the abort flag: once per pass
     for (int64_t c0 = 0; c0 < p->n; c0 += chunk_rows, ++n_chunks) {
         const int64_t nc = std::min<int64_t>(chunk_rows, p->n - c0);
         const int64_t nc_pad = round_up(nc, GEMM_BM);
@@ -1152,7 +1217,14 @@ static int ff_run_chunks(am_pipeline* p, int64_t chunk_rows, float* host_y)
             const double rounds = (double)(nc_pad / GEMM_BM) * std::max(1, m0->max_width / 256) / 256.0;
             if (std::ceil(rounds) / rounds > 1.04) n_chains = (int)max_chains;
         }
-        if (n_chains > 1) {
+        if (stack_ok && nc_pad >= ff_stack_min_rows() && nc_pad <= p->stack_rows) {
+            // one launch per member: a work queue over (layer, row tile, column tile) -- the layers' tails overlap, one partial round per network
+            for (int mi = 0; mi < (int)p->members.size(); ++mi) {
+                AM_TRY(ff_member_forward_stack(p, mi, nc_pad, p->d_acc.as<float>()));
+                if (p->combine == AM_COMBINE_LOGPOST) AM_TRY(member_finish(p, mi, nc));
+            }
+            AM_TRY(final_finish(p, nc, p->d_out.as<float>() + c0 * m0->C, nullptr));
+        } else if (n_chains > 1) {
             if (!p->ev_fork) { HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming)); }
             for (auto& ev : p->ev_chain) if (!ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             hipStream_t streams[4] = {e->stream, e->stream2, e->chain[0], e->chain[1]};
@@ -1204,6 +1276,25 @@ static int ff_run_chunks(am_pipeline* p, int64_t chunk_rows, float* host_y)
     return AM_OK;
 }
 
+// After a synchronisation: did a gemm_stack_kernel launch give up on a wait?  Then the pass is invalid: repeat it on the
+// per-layer launches (same bits), keep this pipeline on them, and say so -- never a wrong result, never a hung GPU.
+static int ff_stack_check(am_pipeline* p, bool* reran = nullptr)
+{
+    if (reran) *reran = false;
+    if (p->mode != 1 || !p->used_stack || !p->d_ffsync.p) return AM_OK;
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, p->d_ffsync.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (!flag) return AM_OK;
+    fprintf(stderr, "libamfwd: the single-launch Linear stack gave up on an inter-workgroup wait; repeating the pass on the per-layer launches\n");
+    ++g_lstm_fallbacks;
+    p->stack_off = true;
+    const int rc = ff_run_chunks(p, FF_CHUNK_ROWS, nullptr);
+    if (rc != AM_OK) { p->results_valid = false; return rc; }
+    AM_TRY(sync_all(p->e));
+    if (reran) *reran = true;
+    return AM_OK;
+}
+
 extern "C" int am_ff_run(am_pipeline* p)
 {
     if (!p || p->mode != 1) return fail(AM_EINVAL, "am_ff_run: nothing uploaded (am_ff_upload)");
@@ -1235,6 +1326,12 @@ extern "C" int am_ff_download(am_pipeline* p, float* y)
     AM_TRY(join_streams(e));
     if (p->n > 0) HIP_TRY(hipMemcpyAsync(y, p->d_out.p, sizeof(float) * p->n * p->members[0]->C, hipMemcpyDeviceToHost, e->stream));
     AM_TRY(sync_all(e));
+    bool reran = false;
+    AM_TRY(ff_stack_check(p, &reran));   // (checked after the copy: costs the normal case nothing)
+    if (reran && p->n > 0) {
+        HIP_TRY(hipMemcpyAsync(y, p->d_out.p, sizeof(float) * p->n * p->members[0]->C, hipMemcpyDeviceToHost, e->stream));
+        AM_TRY(sync_all(e));
+    }
     return AM_OK;
 }
 
@@ -1385,7 +1482,6 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
 }
 
 static int lstm_enqueue(am_pipeline* p);
-static std::atomic<int> g_lstm_fallbacks{0};
 extern "C" int am_lstm_fallback_count(void) { return g_lstm_fallbacks.load(); }
 
 // After a synchronisation: did the persistent recurrent kernel give up on a wait (lstm_persist_kernel's abort flag)?
@@ -2002,5 +2098,6 @@ extern "C" int am_decode_pipeline(am_decoder* d, am_pipeline* p, const int64_t* 
     HIP_TRY(hipSetDevice(d->e->device));
     AM_TRY(join_streams(d->e));
     if (p->mode == 2 && p->used_persist) { AM_TRY(sync_all(d->e)); AM_TRY(persist_check(p)); }
+    if (p->mode == 1 && p->used_stack) { AM_TRY(sync_all(d->e)); AM_TRY(ff_stack_check(p)); }
     return decode_device(d, p->d_out.as<float>(), d->S, offsets, n_utts, seg_begin, seg_end, seg_tri, seg_count);
 }

@@ -17,7 +17,8 @@ enum KernelId {
     K_VITERBI = 7,     // triphone Viterbi decode, one workgroup per utterance
     K_SPLIT_CONVERT = 8, // f32 -> hi/lo halves (split-f16 mode)
     K_GEMM_SPLIT = 9,  // Linear layers on the f16 pipe with hi/lo operands (split-f16 mode)
-    K_COUNT = 10
+    K_GEMM_STACK = 10, // the whole Linear stack of a network in one launch (work queue over layers and tiles)
+    K_COUNT = 11
 };
 
 constexpr int GEMM_BM = 256;  // rows per block tile: every activation matrix is padded to a multiple of this
@@ -44,6 +45,26 @@ struct GemmArgs {
 };
 hipError_t init_kernels();  // once per device after hipSetDevice
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
+
+// The Linear stack of one network as ONE launch: work queue over (layer, row tile, column tile), see gemm_stack_kernel.
+constexpr int GEMM_STACK_MAX_HIDDEN = 8;
+struct GemmStackLayer {
+    const float* W; const float* bias; float* C;   // [N_pad, ldw], [N_pad], [M_pad, ldc]
+    int ldw, ldc, tiles_n, nk;                     // column tiles (256 wide; output layer 256 or 384), K stages (of 32; 384-wide output: of 16)
+    int item0;                                     // number of this layer's first item
+};
+struct GemmStackArgs {
+    GemmStackLayer L[GEMM_STACK_MAX_HIDDEN + 1];     // hidden layers 0 .. n_hidden-1 (Linear + bias + act), then the output layer
+    const float* A0; int lda0;   // layer 0's input rows (written by an earlier launch)
+    int n_hidden, tiles_m, act;
+    int out_epi; float out_alpha;
+    unsigned* done;              // [n_hidden][tiles_m] finished column tiles per (hidden layer, row tile); zero before the launch
+    int* queue;                  // item counter, zero before the launch
+    int* abort_flag;             // set when a wait ran into its bound (the pass is then invalid)
+    int n_items;
+    int test_extra;              // added to every wait's target (0; the give-up test sets 1)
+};
+hipError_t launch_gemm_stack(hipStream_t s, const GemmStackArgs& a, int out_n_pad);
 
 // split-f16 precision mode (see gemm_nt_split_kernel): operands are hi/lo half matrices
 struct SplitGemmArgs {

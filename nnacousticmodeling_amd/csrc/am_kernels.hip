@@ -12,6 +12,10 @@ namespace am {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int LSTM_P_TIMEOUT = 200000000;   // ticks of s_memrealtime (100 MHz): 2 s, the bound of every inter-workgroup wait
+__device__ __forceinline__ unsigned ld_agent_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 #define AM_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define AM_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -97,10 +101,12 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NI], const
     }
 }
 
-template <int BN, int BK>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(
-    const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ bias,
-    float* __restrict__ C, int ldc, int tiles_n, int nk, int act, int epi, float alpha, int row_p, int row_skip, int* __restrict__ queue, int n_tiles)
+// One block tile's products: acc = A[m0.., :] * W[n0.., :]^T over nk stages of BK.  AUX = 16 loads the A operand with sc1 (rows
+// another workgroup of the SAME launch stored write-through, gemm_stack_kernel); SWAP feeds W as the MFMA's row operand, so a
+// lane ends up holding 4 consecutive COLUMNS of one output row (C/D map transposed) -- every element is the same fmaf chain in k.
+template <int BN, int BK, int AUX, bool SWAP>
+__device__ __forceinline__ void gemm_tile_products(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, int m0, int n0, int nk,
+                                                   int row_p, int row_skip, char* smem, f32x16 (&acc)[GEMM_BM / GEMM_WM / 32][BN / GEMM_WN / 32])
 {
     constexpr int BM = GEMM_BM, NW = GEMM_WM * GEMM_WN;
     constexpr int MI = BM / GEMM_WM / 32, NI = BN / GEMM_WN / 32;
@@ -115,27 +121,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(
     constexpr int SW_SHIFT = (BK == 32) ? 1 : 2;    // 128-B rows: (row>>1)&7 ; 64-B rows: (row>>2)&3
     constexpr int SW_MASK = CH - 1;
     static_assert(LOADS <= SLOTS, "not enough MFMA groups to interleave the LDS-DMA issue");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous run
-    // of tiles, n fastest, so the blocks resident on one XCD share A panels and W in its L2.
-    // Work-queue mode (queue != nullptr): the blocks pull tiles from a global counter instead.  Workgroups are dealt to the XCDs
-    // statically, so when other kernels hold some XCDs (the persistent recurrent kernel's last row groups), the blocks dealt to
-    // the free XCDs do ALL the work and the late-comers find the queue empty; which block computes a tile never changes a bit.
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
-    int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    for (;;) {
-    if (queue) {           // the tile number travels through the first word of the (idle) stage buffers: no LDS beyond the stages' (two blocks per CU use all 160 KiB)
-        __syncthreads();   // the previous tile's LDS reads are done
-        if (threadIdx.x == 0) *(volatile int*)smem = atomicAdd(queue, 1);
-        __syncthreads();
-        tile = *(volatile int*)smem;
-        __syncthreads();   // everyone has read it before the first LDS-DMA piece lands there
-        if (tile >= n_tiles) break;
-    }
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / GEMM_WN, wn = wave % GEMM_WN;
@@ -159,11 +144,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(
         gw[j] = W + (size_t)(n0 + r) * ldw + c * 4;
     }
     auto issue = [&](char* sbase, int k0, int l) {   // l-th LDS-DMA piece of a stage (wave-uniform LDS address)
-        if (l < A_PER_WAVE) __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(ga[l] + k0), AM_LDS_PTR(sbase + (l * NW + wave) * 1024), 16, 0, 0);
+        if (l < A_PER_WAVE) __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(ga[l] + k0), AM_LDS_PTR(sbase + (l * NW + wave) * 1024), 16, 0, AUX);
         else __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(gw[l - A_PER_WAVE] + k0), AM_LDS_PTR(sbase + BM * BK * 4 + ((l - A_PER_WAVE) * NW + wave) * 1024), 16, 0, 0);
     };
 
-    f32x16 acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -209,16 +193,25 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][mi][j], bv[t & 1][ni][j], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t & 1][ni][j], av[t & 1][mi][j], acc[mi][ni], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][mi][j], bv[t & 1][ni][j], acc[mi][ni], 0, 0, 0);
                 const int slot = t * 4 + j;
                 if (slot % EVERY == 0 && slot / EVERY < LOADS) issue(sbase, k0, slot / EVERY);
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the tail prefetch before the wave ends
+}
 
-    // epilogue: one uniform dispatch on the mode, then straight-line code
-    const int erow = m0 + wm * (BM / GEMM_WM) + 4 * lh, ecol = n0 + wn * (BN / GEMM_WN) + li;
+template <int BN>
+__device__ __forceinline__ void gemm_tile_epilogue(const f32x16 (&acc)[GEMM_BM / GEMM_WM / 32][BN / GEMM_WN / 32], const float* __restrict__ bias,
+                                                   float* __restrict__ C, int ldc, int m0, int n0, int act, int epi, float alpha)
+{
+    constexpr int MI = GEMM_BM / GEMM_WM / 32, NI = BN / GEMM_WN / 32;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / GEMM_WN, wn = wave % GEMM_WN, li = lane & 31, lh = lane >> 5;
+    // one uniform dispatch on the mode, then straight-line code
+    const int erow = m0 + wm * (GEMM_BM / GEMM_WM) + 4 * lh, ecol = n0 + wn * (BN / GEMM_WN) + li;
     if (epi == EPI_ACT) {
         if (act == 0) gemm_epilogue<0, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
         else if (act == 1) gemm_epilogue<1, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
@@ -226,6 +219,39 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(
     } else if (epi == EPI_LINEAR) gemm_epilogue<3, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
     else if (epi == EPI_SCALE) gemm_epilogue<4, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
     else gemm_epilogue<5, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
+}
+
+template <int BN, int BK>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ bias,
+    float* __restrict__ C, int ldc, int tiles_n, int nk, int act, int epi, float alpha, int row_p, int row_skip, int* __restrict__ queue, int n_tiles)
+{
+    constexpr int BM = GEMM_BM;
+    constexpr int MI = BM / GEMM_WM / 32, NI = BN / GEMM_WN / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous run
+    // of tiles, n fastest, so the blocks resident on one XCD share A panels and W in its L2.
+    // Work-queue mode (queue != nullptr): the blocks pull tiles from a global counter instead.  Workgroups are dealt to the XCDs
+    // statically, so when other kernels hold some XCDs (the persistent recurrent kernel's last row groups), the blocks dealt to
+    // the free XCDs do ALL the work and the late-comers find the queue empty; which block computes a tile never changes a bit.
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
+    int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    for (;;) {
+    if (queue) {           // the tile number travels through the first word of the (idle) stage buffers
+        __syncthreads();   // the previous tile's LDS reads are done
+        if (threadIdx.x == 0) *(volatile int*)smem = atomicAdd(queue, 1);
+        __syncthreads();
+        tile = *(volatile int*)smem;
+        __syncthreads();   // everyone has read it before the first LDS-DMA piece lands there
+        if (tile >= n_tiles) break;
+    }
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    f32x16 acc[MI][NI];
+    gemm_tile_products<BN, BK, 0, false>(A, lda, W, ldw, m0, n0, nk, row_p, row_skip, smem, acc);
+    gemm_tile_epilogue<BN>(acc, bias, C, ldc, m0, n0, act, epi, alpha);
     if (!queue) break;
     }
 }
@@ -236,6 +262,7 @@ constexpr int GEMM_LDS_384 = 2 * (GEMM_BM + 384) * 16 * 4;  //  80 KiB
 hipError_t init_split_kernels();
 hipError_t init_lstm_kernels();
 hipError_t init_rec_kernels();
+hipError_t init_stack_kernel();
 
 hipError_t init_kernels()
 {
@@ -248,7 +275,9 @@ hipError_t init_kernels()
     // per device: allow the GEMM's large dynamic LDS
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_f32_kernel<256, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_256);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)gemm_nt_f32_kernel<384, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_384);
+    e = hipFuncSetAttribute((const void*)gemm_nt_f32_kernel<384, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_384);
+    if (e != hipSuccess) return e;
+    return init_stack_kernel();
 }
 
 int gemm_n_pad(int n)
@@ -273,6 +302,140 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g)
         hipLaunchKernelGGL((gemm_nt_f32_kernel<384, 16>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_384, s,
                            g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 16, g.act, g.epi, g.alpha, g.row_p, g.row_skip, g.queue, n_tiles);
     } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The whole Linear stack of one network in ONE launch (gemm_stack_kernel): a work queue over (layer, row tile, column tile).
+//
+// Why: a layer launched on its own runs in whole rounds of 256 tiles -- 57,919 rows x 1024 = 908 tiles = 3.55 rounds, run as
+// 4 -- and every launch ends in a ragged tail.  Row tile r of layer l+1 needs only row tile r of layer l, so here the 256
+// resident workgroups pull items from ONE counter, layer-major, and the tail of layer l runs beside the head of layer l+1:
+// one partial round per network instead of one per layer.
+//   item  = atomicAdd(queue)            (layer-major, row tile, column tile fastest)
+//   wait  : done[l-1][row tile] == column tiles of layer l-1        (one lane polls, sc1; then the workgroup's barrier)
+//   tile  : the same products and epilogue as gemm_nt_f32_kernel -- which workgroup computes a tile never changes a bit
+//   hand-off: hidden activations are stored write-through (sc1) and read by sc1 LDS-DMA; after every storing wave's
+//             vmcnt(0) and the workgroup's barrier ONE lane adds 1 to done[l][row tile] (agent scope) -- at the top of the next
+//             iteration, so the drain costs nothing extra (MI355X_MICROARCH.md, inter-workgroup visibility, first table row).
+// Every hidden layer has its OWN activation plane: a plane re-written inside the launch could be served stale from an XCD's
+// L2 that read it two layers earlier.  No deadlock without co-residency: items are pulled in order and an item only waits for
+// items with smaller numbers, which resident workgroups hold.  Waits are bounded like the recurrent kernel's (abort flag).
+// ---------------------------------------------------------------------------------------------------
+template <int MODE, int MI, int NI>
+__device__ __forceinline__ void gemm_epilogue_handoff(const f32x16 (&acc)[MI][NI], const float* __restrict__ bias, float* __restrict__ Ctile, int ldc, int wm, int wn, int li, int lh)
+{
+    // lane (li, lh) holds, for every (mi, ni, g): row wm*64 + mi*32 + li, columns wn*128 + ni*32 + 8g + 4lh .. +3 (SWAP map)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Ctile, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const unsigned rowb = (unsigned)(wm * (GEMM_BM / GEMM_WM) + mi * 32 + li) * (unsigned)ldc;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = wn * (NI * 32) + ni * 32 + 8 * g + 4 * lh;
+                const f32x4 bv = *(const f32x4*)(bias + col);
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = acc[mi][ni][4 * g + j] + bv[j];
+                    if (MODE == 0) x = fmaxf(x, 0.0f);
+                    else if (MODE == 1) x = am_sigmoid(x);
+                    else x = tanhf(x);
+                    v[j] = x;
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)((rowb + (unsigned)col) * 4u), 0, 16 /* sc1 */);
+            }
+        }
+    }
+}
+
+template <bool OUT_WIDE>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_stack_kernel(const GemmStackArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_item, s_abort;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_abort = 0;
+    int publish = -1;            // tid 0: counter of the hidden tile this workgroup stored last, not yet signalled
+    for (;;) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's (write-through) stores of the previous tile have left
+        __syncthreads();                                    // ... every wave's; the previous tile's LDS reads are done too
+        if (tid == 0) {
+            if (publish >= 0) __hip_atomic_fetch_add(a.done + publish, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_item = atomicAdd(a.queue, 1);
+        }
+        __syncthreads();
+        const int item = s_item;
+        if (item >= a.n_items) break;
+        int l = 0;
+#pragma unroll
+        for (int j = 1; j <= GEMM_STACK_MAX_HIDDEN; ++j) if (j <= a.n_hidden && item >= a.L[j].item0) l = j;
+        const GemmStackLayer& Ly = a.L[l];
+        const int local = item - Ly.item0;
+        const int tm = local / Ly.tiles_n, tn = local - tm * Ly.tiles_n;
+        if (l > 0) {
+            if (tid == 0) {
+                const unsigned* c = a.done + (size_t)(l - 1) * a.tiles_m + tm;
+                const unsigned target = (unsigned)(a.L[l - 1].tiles_n + a.test_extra);
+                if (ld_agent_u32(c) < target) {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    int it = 0;
+                    while (ld_agent_u32(c) < target) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if ((++it & 63) == 0 && (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                                                __builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)LSTM_P_TIMEOUT)) {
+                            __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            s_abort = 1;
+                            break;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_abort) break;
+        }
+        const float* A = l > 0 ? a.L[l - 1].C : a.A0;
+        const int lda = l > 0 ? a.L[l - 1].ldc : a.lda0;
+        const int m0 = tm * GEMM_BM;
+        if (l < a.n_hidden) {
+            constexpr int MI = GEMM_BM / GEMM_WM / 32, NI = 256 / GEMM_WN / 32;
+            f32x16 acc[MI][NI];
+            const int n0 = tn * 256;
+            gemm_tile_products<256, 32, 16, true>(A, lda, Ly.W, Ly.ldw, m0, n0, Ly.nk, 0, 0, smem, acc);
+            const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            float* Ct = Ly.C + (size_t)m0 * Ly.ldc + n0;
+            if (a.act == 0) gemm_epilogue_handoff<0, MI, NI>(acc, Ly.bias + n0, Ct, Ly.ldc, wave / GEMM_WN, wave % GEMM_WN, lane & 31, lane >> 5);
+            else if (a.act == 1) gemm_epilogue_handoff<1, MI, NI>(acc, Ly.bias + n0, Ct, Ly.ldc, wave / GEMM_WN, wave % GEMM_WN, lane & 31, lane >> 5);
+            else gemm_epilogue_handoff<2, MI, NI>(acc, Ly.bias + n0, Ct, Ly.ldc, wave / GEMM_WN, wave % GEMM_WN, lane & 31, lane >> 5);
+            publish = l * a.tiles_m + tm;
+        } else {
+            constexpr int BN = OUT_WIDE ? 384 : 256, BK = OUT_WIDE ? 16 : 32;
+            constexpr int MI = GEMM_BM / GEMM_WM / 32, NI = BN / GEMM_WN / 32;
+            f32x16 acc[MI][NI];
+            const int n0 = tn * BN;
+            gemm_tile_products<BN, BK, 16, false>(A, lda, Ly.W, Ly.ldw, m0, n0, Ly.nk, 0, 0, smem, acc);
+            gemm_tile_epilogue<BN>(acc, Ly.bias, Ly.C, Ly.ldc, m0, n0, a.act, a.out_epi, a.out_alpha);   // plain stores: read by later launches only
+            publish = -1;
+        }
+    }
+}
+
+hipError_t init_stack_kernel()
+{
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_stack_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_256);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)gemm_stack_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_256);
+}
+
+hipError_t launch_gemm_stack(hipStream_t s, const GemmStackArgs& a, int out_n_pad)
+{
+    if (a.n_hidden < 1 || a.n_hidden > GEMM_STACK_MAX_HIDDEN || a.tiles_m <= 0 || a.n_items <= 0) return hipErrorInvalidValue;
+    const int grid = std::min(a.n_items, 256);   // one workgroup per CU
+    if (out_n_pad % 256 == 0) hipLaunchKernelGGL(gemm_stack_kernel<false>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_256, s, a);
+    else if (out_n_pad % 384 == 0) hipLaunchKernelGGL(gemm_stack_kernel<true>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_256, s, a);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -1237,10 +1400,6 @@ __global__ __launch_bounds__(512) void lstm_thin_kernel(const LstmWavefrontArgs 
 // Every wait is bounded (2 s of the 100 MHz counter): a timeout raises `abort_flag`, every workgroup leaves, the host
 // reports an error instead of hanging the GPU.
 // ---------------------------------------------------------------------------------------------------
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr int LSTM_P_TIMEOUT = 200000000;   // ticks of s_memrealtime (100 MHz): 2 s
-
-__device__ __forceinline__ unsigned ld_agent_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ f32x4 ld_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
 {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16 /* sc1 */));
