@@ -174,8 +174,8 @@ def timed_runs(eng, fn, steps, warmup, barrier=None):
 
 
 def gemm_roofline(prof, flops_total):
-    calls = sum(prof[k][0] for k in ("gemm_hidden", "gemm_out") if k in prof)
-    ms = sum(prof[k][1] for k in ("gemm_hidden", "gemm_out") if k in prof)
+    calls = sum(prof[k][0] for k in ("gemm_hidden", "gemm_out", "gemm_stack") if k in prof)
+    ms = sum(prof[k][1] for k in ("gemm_hidden", "gemm_out", "gemm_stack") if k in prof)
     achieved = flops_total / (ms * 1e-3) / 1e12 if ms > 0 else None
     return calls, ms, achieved
 
@@ -215,7 +215,7 @@ def secondary_records(eng, ft, params, layers, x, steps):
                      "roofline": {"bound": "mfma", "kernel": "whole step (at this size the rows go down the layers as two chains on two streams, so the GEMM launches overlap "
                                   "and their summed durations exceed the wall time: the fraction is flop / wall time / peak)",
                                   "achieved": whole, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": whole / PEAK_F32_MFMA_TFLOPS},
-                     "gemm_launch_ms_sum_per_step": sum(prof[k_][1] for k_ in ("gemm_hidden", "gemm_out") if k_ in prof) / k}
+                     "gemm_launch_ms_sum_per_step": sum(prof[k_][1] for k_ in ("gemm_hidden", "gemm_out", "gemm_stack") if k_ in prof) / k}
     p.close()
     m4.close()
     # (iii) BASELINE configs[2]: 6x2048 on 440 spliced + 100 i-vector columns

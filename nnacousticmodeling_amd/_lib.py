@@ -66,6 +66,7 @@ SIGNATURES = {
     "am_lstm_download": (C.c_int, [C.c_void_p, c_float_p]),
     "am_forward_lstm": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_int64_p, C.c_int, C.c_int, c_float_p]),
     "am_lstm_stamps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_int_p, c_int_p]),
+    "am_ff_stack_stamps": (C.c_int, [C.c_void_p, C.c_void_p]),
     "am_lstm_fallback_count": (C.c_int, []),
     "am_pipeline_output_shape": (C.c_int, [C.c_void_p, c_int64_p, c_int_p]),
     "am_frontend_apply": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int64, C.c_int, C.c_int, c_float_p]),

@@ -141,7 +141,7 @@ struct am_pipeline {
     bool has_ivec = false;
     DevBuf d_x, d_ivec, d_in, d_in_s, d_act0, d_act1, d_acc, d_acc2, d_out;
     // the Linear stack as one work-queue launch (gemm_stack_kernel): one activation plane per hidden layer + its counters
-    DevBuf d_stack, d_ffsync;          // float [planes][stack_rows * stack_width]; unsigned {abort flag, queue, done[hidden][row tiles]}
+    DevBuf d_stack, d_ffsync;          // float [planes][stack_rows * stack_width]; unsigned {abort flag, 8 queues, done[hidden][row tiles]}
     int64_t stack_rows = 0; int stack_width = 0, stack_planes = 0;
     bool used_stack = false;           // the current results came from gemm_stack_kernel (its abort flag is checked before they are handed out)
     bool stack_off = false;            // a stack launch gave up on a wait: this pipeline stays on the per-layer launches
@@ -968,16 +968,17 @@ static int tdnn_member_forward_split(am_pipeline* p, int mi, int64_t frames, flo
 
 static std::atomic<int> g_lstm_fallbacks{0};   // passes a persistent kernel (recurrent, or the Linear stack) gave up on and the per-launch kernels repeated (am_lstm_fallback_count)
 
-// The whole Linear stack of a member as ONE work-queue launch (gemm_stack_kernel) instead of one launch per layer: AM_FF_STACK = 0 off,
-// 1 for resident passes of at least 16 row tiles, 2 whatever the size (off by default while it is slower than the row chains).
-static int ff_stack_mode() { return (int)env_int("AM_FF_STACK", 0); }   // read on every call: the tests switch it
-static int64_t ff_stack_min_rows() { return ff_stack_mode() >= 2 ? GEMM_BM : 16 * GEMM_BM; }
+// The whole Linear stack of a member as ONE work-queue launch (gemm_stack_kernel) instead of one launch per layer (AM_FF_STACK=0:
+// the per-layer launches).  Measured faster at every size: 1,024 rows 1.05 against 1.24 ms, 57,919 rows 5.10 against 5.30 (two row
+// chains), 196,608 rows 16.30 against 16.63 ms (4x1024).
+constexpr int FF_SYNC_QUEUES = 32, FF_SYNC_DONE = FF_SYNC_QUEUES + 8 * GEMM_STACK_QSTRIDE;   // words of d_ffsync: [0] abort flag, the queue counters, the arrival counters
+static int ff_stack_mode() { return (int)env_int("AM_FF_STACK", 1); }   // read on every call: the tests switch it
 static bool ff_stack_shape_ok(const am_model* m)
 {
     if (m->tdnn || m->n_layers < 1 || m->n_layers > GEMM_STACK_MAX_HIDDEN) return false;
     for (int l = 0; l < m->n_layers; ++l) if (m->L[l].out_pad % 256 || m->L[l].in_pad % 32) return false;
     const Layer& out = m->L[m->n_layers];
-    return out.out_pad % 256 == 0 || out.out_pad % 384 == 0;
+    return out.out_pad % 256 == 0 || out.out_pad % 192 == 0;
 }
 
 extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, int64_t n, int halo_lo, int halo_hi)
@@ -1029,9 +1030,9 @@ extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, i
     // one plane per hidden layer for the single-launch form of the stack (a plane re-written inside a launch could be read stale)
     int planes = 0;
     for (auto* m : p->members) if (ff_stack_shape_ok(m)) planes = std::max(planes, m->n_layers);
-    if (planes > 0 && ff_stack_mode() > 0 && rows >= ff_stack_min_rows()) {
+    if (planes > 0 && ff_stack_mode() > 0) {
         AM_TRY(p->d_stack.ensure(sizeof(float) * (size_t)planes * rows * width));
-        AM_TRY(p->d_ffsync.ensure(sizeof(unsigned) * (2 + (size_t)planes * (rows / GEMM_BM))));
+        AM_TRY(p->d_ffsync.ensure(sizeof(unsigned) * (FF_SYNC_DONE + (size_t)planes * (rows / GEMM_BM))));
         p->stack_rows = rows; p->stack_width = width; p->stack_planes = planes;
     } else p->stack_planes = 0;
     }
@@ -1062,18 +1063,23 @@ static int ff_member_forward_stack(am_pipeline* p, int mi, int64_t rows_pad, flo
             S.C = p->d_stack.as<float>() + (size_t)l * plane; S.ldc = Ly.out_pad; S.tiles_n = Ly.out_pad / 256; S.nk = Ly.in_pad / 32;
         } else {
             const bool wide = Ly.out_pad % 256 != 0;
-            S.C = acc; S.ldc = m->C_pad; S.tiles_n = Ly.out_pad / (wide ? 384 : 256); S.nk = Ly.in_pad / (wide ? 16 : 32);
+            S.C = acc; S.ldc = m->C_pad; S.tiles_n = Ly.out_pad / (wide ? 192 : 256); S.nk = Ly.in_pad / 32;
         }
-        S.item0 = item;
-        item += tiles_m * S.tiles_n;
+        S.cum_n = item;
+        item += S.tiles_n;
     }
     a.A0 = p->d_in.as<float>(); a.lda0 = m->in_pad;
     a.n_hidden = m->n_layers; a.tiles_m = tiles_m; a.act = m->act;
     a.out_epi = epilogue_mode(p, mi, &a.out_alpha);
     unsigned* sync = p->d_ffsync.as<unsigned>();
-    a.abort_flag = (int*)sync; a.queue = (int*)sync + 1; a.done = sync + 2; a.n_items = item;
-    a.test_extra = env_int("AM_FF_TEST_TIMEOUT", 0) ? 1 : 0;   // test hook: arrival targets nobody reaches -> the waits must time out
-    HIP_TRY(hipMemsetAsync(sync + 1, 0, sizeof(unsigned) * (1 + (size_t)m->n_layers * tiles_m), e->stream));
+    a.abort_flag = (int*)sync; a.queues = (int*)sync + FF_SYNC_QUEUES; a.done = sync + FF_SYNC_DONE; a.cum_total = item;
+    a.test_extra = env_int("AM_FF_TEST_TIMEOUT", 0) ? 1 : 0;
+    if (env_int("AM_FF_STAMPS", 0)) {   // diagnostic timeline of this launch (am_ff_stack_stamps)
+        AM_TRY(p->d_stamps.ensure(sizeof(unsigned long long) * 8 * 256));
+        HIP_TRY(hipMemsetAsync(p->d_stamps.p, 0, sizeof(unsigned long long) * 8 * 256, e->stream));
+        a.stamps = p->d_stamps.as<unsigned long long>();
+    }   // test hook: arrival targets nobody reaches -> the waits must time out
+    HIP_TRY(hipMemsetAsync(sync + FF_SYNC_QUEUES, 0, sizeof(unsigned) * (FF_SYNC_DONE - FF_SYNC_QUEUES + (size_t)m->n_layers * tiles_m), e->stream));
     const int out_pad = m->L[m->n_layers].out_pad;
     AM_TRY(run_kernel(e, K_GEMM_STACK, [&] { return launch_gemm_stack(e->stream, a, out_pad); }));
     p->used_stack = true;
@@ -1190,7 +1196,7 @@ static int ff_run_chunks(am_pipeline* p, int64_t chunk_rows, float* host_y)
     }
     if (m0->tdnn) chunk_rows = std::min<int64_t>(chunk_rows, tdnn_chunk_frames(m0));
     p->used_stack = false;
-    bool stack_ok = !host_y && !split && !p->stack_off && p->stack_planes > 0 && ff_stack_mode() > 0;
+    bool stack_ok = !split && !p->stack_off && p->stack_planes > 0 && ff_stack_mode() > 0;
     for (auto* m : p->members) stack_ok = stack_ok && ff_stack_shape_ok(m) && m->n_layers <= p->stack_planes && m->max_width <= p->stack_width;
     if (stack_ok) HIP_TRY(hipMemsetAsync(p->d_ffsync.p, 0, sizeof(unsigned), e->stream));   // the abort flag: once per pass
     for (int64_t c0 = 0; c0 < p->n; c0 += chunk_rows, ++n_chunks) {
@@ -1217,7 +1223,7 @@ static int ff_run_chunks(am_pipeline* p, int64_t chunk_rows, float* host_y)
             const double rounds = (double)(nc_pad / GEMM_BM) * std::max(1, m0->max_width / 256) / 256.0;
             if (std::ceil(rounds) / rounds > 1.04) n_chains = (int)max_chains;
         }
-        if (stack_ok && nc_pad >= ff_stack_min_rows() && nc_pad <= p->stack_rows) {
+        if (stack_ok && nc_pad <= p->stack_rows) {
             // one launch per member: a work queue over (layer, row tile, column tile) -- the layers' tails overlap, one partial round per network
             for (int mi = 0; mi < (int)p->members.size(); ++mi) {
                 AM_TRY(ff_member_forward_stack(p, mi, nc_pad, p->d_acc.as<float>()));
@@ -1278,7 +1284,7 @@ static int ff_run_chunks(am_pipeline* p, int64_t chunk_rows, float* host_y)
 
 // After a synchronisation: did a gemm_stack_kernel launch give up on a wait?  Then the pass is invalid: repeat it on the
 // per-layer launches (same bits), keep this pipeline on them, and say so -- never a wrong result, never a hung GPU.
-static int ff_stack_check(am_pipeline* p, bool* reran = nullptr)
+static int ff_stack_check(am_pipeline* p, bool* reran = nullptr, int64_t chunk_rows = 0, float* host_y = nullptr)
 {
     if (reran) *reran = false;
     if (p->mode != 1 || !p->used_stack || !p->d_ffsync.p) return AM_OK;
@@ -1288,10 +1294,19 @@ static int ff_stack_check(am_pipeline* p, bool* reran = nullptr)
     fprintf(stderr, "libamfwd: the single-launch Linear stack gave up on an inter-workgroup wait; repeating the pass on the per-layer launches\n");
     ++g_lstm_fallbacks;
     p->stack_off = true;
-    const int rc = ff_run_chunks(p, FF_CHUNK_ROWS, nullptr);
+    const int rc = ff_run_chunks(p, chunk_rows > 0 ? chunk_rows : FF_CHUNK_ROWS, host_y);
     if (rc != AM_OK) { p->results_valid = false; return rc; }
     AM_TRY(sync_all(p->e));
     if (reran) *reran = true;
+    return AM_OK;
+}
+
+extern "C" int am_ff_stack_stamps(am_pipeline* p, unsigned long long* out)
+{
+    if (!p || !out || p->mode != 1 || !p->used_stack || !p->d_stamps.p) return fail(AM_EINVAL, "am_ff_stack_stamps: no stamped single-launch pass (AM_FF_STAMPS=1, am_ff_run)");
+    HIP_TRY(hipSetDevice(p->e->device));
+    AM_TRY(sync_all(p->e));
+    HIP_TRY(hipMemcpy(out, p->d_stamps.p, sizeof(unsigned long long) * 8 * 256, hipMemcpyDeviceToHost));
     return AM_OK;
 }
 
@@ -1343,6 +1358,7 @@ extern "C" int am_forward_ff(am_pipeline* p, const float* x, const float* ivec, 
     AM_TRY(ff_run_chunks(p, FF_PIPE_ROWS, y));   // download of chunk c overlaps the compute of chunk c+1
     p->results_valid = true;
     AM_TRY(sync_all(p->e));
+    AM_TRY(ff_stack_check(p, nullptr, FF_PIPE_ROWS, y));   // (repeats the pass on the per-layer launches if a stack launch gave up)
     int over = 0;
     AM_TRY(am_pipeline_overflowed(p, &over));
     if (over) {   // an activation did not fit f16: repeat the pass on the exact f32 path

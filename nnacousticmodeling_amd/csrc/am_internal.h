@@ -50,19 +50,21 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
 constexpr int GEMM_STACK_MAX_HIDDEN = 8;
 struct GemmStackLayer {
     const float* W; const float* bias; float* C;   // [N_pad, ldw], [N_pad], [M_pad, ldc]
-    int ldw, ldc, tiles_n, nk;                     // column tiles (256 wide; output layer 256 or 384), K stages (of 32; 384-wide output: of 16)
-    int item0;                                     // number of this layer's first item
+    int ldw, ldc, tiles_n, nk;                     // column tiles (256 wide; output layer 256 or 192), K stages of 32
+    int cum_n;                                     // column tiles of all the layers before this one
 };
+constexpr int GEMM_STACK_QSTRIDE = 32;             // ints between the eight queue counters (a 128-B line each)
 struct GemmStackArgs {
     GemmStackLayer L[GEMM_STACK_MAX_HIDDEN + 1];     // hidden layers 0 .. n_hidden-1 (Linear + bias + act), then the output layer
     const float* A0; int lda0;   // layer 0's input rows (written by an earlier launch)
     int n_hidden, tiles_m, act;
     int out_epi; float out_alpha;
     unsigned* done;              // [n_hidden][tiles_m] finished column tiles per (hidden layer, row tile); zero before the launch
-    int* queue;                  // item counter, zero before the launch
+    int* queues;                 // eight item counters GEMM_STACK_QSTRIDE ints apart, zero before the launch: queue x holds the row tiles x, x + 8, ...
     int* abort_flag;             // set when a wait ran into its bound (the pass is then invalid)
-    int n_items;
+    int cum_total;               // column tiles of all layers: queue x has (row tiles of x) * cum_total items
     int test_extra;              // added to every wait's target (0; the give-up test sets 1)
+    unsigned long long* stamps;  // diagnostic [workgroups][8] or nullptr: start, end (100 MHz ticks), tiles, ticks waited, waits, stolen tiles, last tile's start, XCC id
 };
 hipError_t launch_gemm_stack(hipStream_t s, const GemmStackArgs& a, int out_n_pad);
 

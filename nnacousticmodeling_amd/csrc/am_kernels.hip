@@ -104,9 +104,11 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NI], const
 // One block tile's products: acc = A[m0.., :] * W[n0.., :]^T over nk stages of BK.  AUX = 16 loads the A operand with sc1 (rows
 // another workgroup of the SAME launch stored write-through, gemm_stack_kernel); SWAP feeds W as the MFMA's row operand, so a
 // lane ends up holding 4 consecutive COLUMNS of one output row (C/D map transposed) -- every element is the same fmaf chain in k.
-template <int BN, int BK, int AUX, bool SWAP>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int BN, int BK, int AUX, bool SWAP, class Hook = NoHook>
 __device__ __forceinline__ void gemm_tile_products(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, int m0, int n0, int nk,
-                                                   int row_p, int row_skip, char* smem, f32x16 (&acc)[GEMM_BM / GEMM_WM / 32][BN / GEMM_WN / 32])
+                                                   int row_p, int row_skip, char* smem, f32x16 (&acc)[GEMM_BM / GEMM_WM / 32][BN / GEMM_WN / 32],
+                                                   Hook after_first_barrier = Hook())
 {
     constexpr int BM = GEMM_BM, NW = GEMM_WM * GEMM_WN;
     constexpr int MI = BM / GEMM_WM / 32, NI = BN / GEMM_WN / 32;
@@ -168,6 +170,7 @@ __device__ __forceinline__ void gemm_tile_products(const float* __restrict__ A, 
         const int buf = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage kt landed (this wave's pieces) ...
         __builtin_amdgcn_s_barrier();                      // ... and everyone's; everyone is done reading stage kt-1
+        if (kt == 0) after_first_barrier();                // (every wave has drained ALL its earlier memory operations here)
         // prefetch stage kt+1 into the other buffer; the tail re-fetches the last stage into the idle buffer (never read)
         const int kn = kt + 1 < nk ? kt + 1 : nk - 1;
         char* sbase = smem + (buf ^ 1) * STAGE_BYTES;
@@ -312,30 +315,43 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g)
 // 4 -- and every launch ends in a ragged tail.  Row tile r of layer l+1 needs only row tile r of layer l, so here the 256
 // resident workgroups pull items from ONE counter, layer-major, and the tail of layer l runs beside the head of layer l+1:
 // one partial round per network instead of one per layer.
-//   item  = atomicAdd(queue)            (layer-major, row tile, column tile fastest)
+//   item  = atomicAdd(queue of this XCD)   (eight queues: queue x holds the row tiles x, x + 8, ...; layer-major, column tile
+//                                           fastest, so the workgroups of an XCD share A panels in its L2; a dry queue -> the next XCD's)
 //   wait  : done[l-1][row tile] == column tiles of layer l-1        (one lane polls, sc1; then the workgroup's barrier)
 //   tile  : the same products and epilogue as gemm_nt_f32_kernel -- which workgroup computes a tile never changes a bit
 //   hand-off: hidden activations are stored write-through (sc1) and read by sc1 LDS-DMA; after every storing wave's
-//             vmcnt(0) and the workgroup's barrier ONE lane adds 1 to done[l][row tile] (agent scope) -- at the top of the next
-//             iteration, so the drain costs nothing extra (MI355X_MICROARCH.md, inter-workgroup visibility, first table row).
+//             vmcnt(0) and the workgroup's barrier ONE lane adds 1 to done[l][row tile] (agent scope) -- behind the first stage
+//             barrier of the NEXT tile, where that drain has happened anyway; the next item is pulled there too, a tile ahead
+//             (MI355X_MICROARCH.md, inter-workgroup visibility, first table row).
 // Every hidden layer has its OWN activation plane: a plane re-written inside the launch could be served stale from an XCD's
-// L2 that read it two layers earlier.  No deadlock without co-residency: items are pulled in order and an item only waits for
-// items with smaller numbers, which resident workgroups hold.  Waits are bounded like the recurrent kernel's (abort flag).
+// L2 that read it two layers earlier.  No deadlock without co-residency: a queue's items are pulled in order and an item only
+// waits for items of the same queue with smaller numbers, which resident workgroups hold (and a workgroup that has to wait
+// signals the tile it holds back first).  Waits are bounded like the recurrent kernel's (abort flag).
 // ---------------------------------------------------------------------------------------------------
+// Epilogue of a hidden tile: act(acc + bias), stored write-through (sc1) for the workgroups that read it in this launch.
+// With the transposed C/D map (SWAP) a lane holds 4 consecutive columns of one row, but storing those directly writes every
+// 128-B line in four 32-B pieces, and a write-through store of part of a line is a fabric write of its own: measured 11 us per
+// 256 x 256 tile (the whole headline pass 3.3 % slower than with plain stores).  So the block goes through LDS once and leaves
+// as whole lines -- a wave's 64 x 128 block as 2 rows x 512 B per store instruction -- which costs the same as plain stores.
+// Each wave stages 32 rows x 128 columns at a time in its own 17-KB slice (row stride 136 floats: conflict-free b128 writes).
+constexpr int GEMM_STACK_STAGE_LD = 136;
+constexpr int GEMM_STACK_LDS = (GEMM_WM * GEMM_WN) * 32 * GEMM_STACK_STAGE_LD * 4;   // 139,264 B >= the products' two stages
 template <int MODE, int MI, int NI>
-__device__ __forceinline__ void gemm_epilogue_handoff(const f32x16 (&acc)[MI][NI], const float* __restrict__ bias, float* __restrict__ Ctile, int ldc, int wm, int wn, int li, int lh)
+__device__ __forceinline__ void gemm_epilogue_handoff_lines(const f32x16 (&acc)[MI][NI], const float* __restrict__ bias, float* __restrict__ Ctile, int ldc,
+                                                            int wave, int wm, int wn, int lane, char* smem)
 {
-    // lane (li, lh) holds, for every (mi, ni, g): row wm*64 + mi*32 + li, columns wn*128 + ni*32 + 8g + 4lh .. +3 (SWAP map)
+    static_assert(NI * 32 + 8 == GEMM_STACK_STAGE_LD, "stage row = the wave's 128 columns + pad");
+    const int li = lane & 31, lh = lane >> 5;
+    float* stage = (float*)smem + wave * (32 * GEMM_STACK_STAGE_LD);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Ctile, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const unsigned rowb = (unsigned)(wm * (GEMM_BM / GEMM_WM) + mi * 32 + li) * (unsigned)ldc;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int col = wn * (NI * 32) + ni * 32 + 8 * g + 4 * lh;
-                const f32x4 bv = *(const f32x4*)(bias + col);
+                const int col = ni * 32 + 8 * g + 4 * lh;
+                const f32x4 bv = *(const f32x4*)(bias + wn * (NI * 32) + col);
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -345,42 +361,69 @@ __device__ __forceinline__ void gemm_epilogue_handoff(const f32x16 (&acc)[MI][NI
                     else x = tanhf(x);
                     v[j] = x;
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)((rowb + (unsigned)col) * 4u), 0, 16 /* sc1 */);
+                *(f32x4*)(stage + li * GEMM_STACK_STAGE_LD + col) = v;
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = 2 * i + lh;
+            const f32x4 v = *(const f32x4*)(stage + row * GEMM_STACK_STAGE_LD + 4 * li);
+            const unsigned off = (unsigned)(wm * (GEMM_BM / GEMM_WM) + mi * 32 + row) * (unsigned)ldc + (unsigned)(wn * (NI * 32) + 4 * li);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)(off * 4u), 0, 16 /* sc1 */);
         }
     }
 }
 
-template <bool OUT_WIDE>
+template <bool OUT_192>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_stack_kernel(const GemmStackArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int s_item, s_abort;
+    __shared__ int s_queue, s_item, s_ready, s_abort;
     const int tid = threadIdx.x;
     if (tid == 0) s_abort = 0;
-    int publish = -1;            // tid 0: counter of the hidden tile this workgroup stored last, not yet signalled
+    // tid 0's bookkeeping
+    int publish = -1;                                  // counter of the hidden tile this workgroup stored last, not yet signalled
+    int cur_q = blockIdx.x & 7, stolen = 0;            // the queue it pulls from (its XCD's own until that runs dry)
+    int pulled = tid == 0 ? atomicAdd(a.queues + cur_q * GEMM_STACK_QSTRIDE, 1) : 0;
+    unsigned long long st_start = 0, st_wait = 0, st_last = 0; int st_tiles = 0, st_stolen = 0, st_waits = 0;   // diagnostic timeline (a.stamps)
+    if (a.stamps && tid == 0) st_start = __builtin_amdgcn_s_memrealtime();
+    auto rows_of = [&](int q) { return a.tiles_m > q ? (a.tiles_m - q + 7) >> 3 : 0; };   // row tiles of queue q: q, q + 8, ...
+    auto signal = [&] { if (publish >= 0) { __hip_atomic_fetch_add(a.done + publish, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); publish = -1; } };
     for (;;) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's (write-through) stores of the previous tile have left
-        __syncthreads();                                    // ... every wave's; the previous tile's LDS reads are done too
+        __syncthreads();                               // the previous iteration's reads of s_* are done
         if (tid == 0) {
-            if (publish >= 0) __hip_atomic_fetch_add(a.done + publish, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_item = atomicAdd(a.queue, 1);
+            while (stolen < 8 && pulled >= rows_of(cur_q) * a.cum_total) {   // this queue is dry: move on to the next XCD's
+                ++stolen;
+                cur_q = (cur_q + 1) & 7;
+                if (stolen < 8) pulled = atomicAdd(a.queues + cur_q * GEMM_STACK_QSTRIDE, 1);
+            }
+            s_queue = stolen < 8 ? cur_q : -1;
+            s_item = pulled;
         }
         __syncthreads();
-        const int item = s_item;
-        if (item >= a.n_items) break;
+        const int q = s_queue, item = s_item;
+        if (q < 0) break;
+        const int rq = rows_of(q);
         int l = 0;
 #pragma unroll
-        for (int j = 1; j <= GEMM_STACK_MAX_HIDDEN; ++j) if (j <= a.n_hidden && item >= a.L[j].item0) l = j;
+        for (int j = 1; j <= GEMM_STACK_MAX_HIDDEN; ++j) if (j <= a.n_hidden && item >= rq * a.L[j].cum_n) l = j;
         const GemmStackLayer& Ly = a.L[l];
-        const int local = item - Ly.item0;
-        const int tm = local / Ly.tiles_n, tn = local - tm * Ly.tiles_n;
+        const int local = item - rq * Ly.cum_n;
+        const int r = local / Ly.tiles_n, tn = local - r * Ly.tiles_n, tm = q + 8 * r;
         if (l > 0) {
-            if (tid == 0) {
-                const unsigned* c = a.done + (size_t)(l - 1) * a.tiles_m + tm;
-                const unsigned target = (unsigned)(a.L[l - 1].tiles_n + a.test_extra);
-                if (ld_agent_u32(c) < target) {
+            // this item's operand rows: finished?  If not, signal the tile still held back FIRST (two workgroups each waiting for
+            // the other's unsignalled tile would never end), then wait -- bounded
+            const unsigned* c = a.done + (size_t)(l - 1) * a.tiles_m + tm;
+            const unsigned target = (unsigned)(a.L[l - 1].tiles_n + a.test_extra);
+            if (tid == 0) s_ready = ld_agent_u32(c) >= target;
+            __syncthreads();
+            if (!s_ready) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    signal();
                     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    ++st_waits;
                     int it = 0;
                     while (ld_agent_u32(c) < target) {
                         __builtin_amdgcn_s_sleep(4);
@@ -391,50 +434,69 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_stack_kernel(const GemmS
                             break;
                         }
                     }
+                    if (a.stamps) st_wait += __builtin_amdgcn_s_memrealtime() - t0;
                 }
+                __syncthreads();
+                if (s_abort) return;
             }
-            __syncthreads();
-            if (s_abort) break;
         }
+        // behind the first stage's barrier every wave has drained its stores of the previous tile: signal that tile there, and
+        // pull the next item (its number is needed a whole tile later)
+        auto hook = [&] { if (tid == 0) { signal(); pulled = atomicAdd(a.queues + cur_q * GEMM_STACK_QSTRIDE, 1); } };
         const float* A = l > 0 ? a.L[l - 1].C : a.A0;
         const int lda = l > 0 ? a.L[l - 1].ldc : a.lda0;
         const int m0 = tm * GEMM_BM;
+        if (a.stamps && tid == 0) { ++st_tiles; st_stolen += stolen > 0; st_last = __builtin_amdgcn_s_memrealtime(); }
         if (l < a.n_hidden) {
             constexpr int MI = GEMM_BM / GEMM_WM / 32, NI = 256 / GEMM_WN / 32;
             f32x16 acc[MI][NI];
             const int n0 = tn * 256;
-            gemm_tile_products<256, 32, 16, true>(A, lda, Ly.W, Ly.ldw, m0, n0, Ly.nk, 0, 0, smem, acc);
+            gemm_tile_products<256, 32, 16, true>(A, lda, Ly.W, Ly.ldw, m0, n0, Ly.nk, 0, 0, smem, acc, hook);
             const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
             float* Ct = Ly.C + (size_t)m0 * Ly.ldc + n0;
-            if (a.act == 0) gemm_epilogue_handoff<0, MI, NI>(acc, Ly.bias + n0, Ct, Ly.ldc, wave / GEMM_WN, wave % GEMM_WN, lane & 31, lane >> 5);
-            else if (a.act == 1) gemm_epilogue_handoff<1, MI, NI>(acc, Ly.bias + n0, Ct, Ly.ldc, wave / GEMM_WN, wave % GEMM_WN, lane & 31, lane >> 5);
-            else gemm_epilogue_handoff<2, MI, NI>(acc, Ly.bias + n0, Ct, Ly.ldc, wave / GEMM_WN, wave % GEMM_WN, lane & 31, lane >> 5);
-            publish = l * a.tiles_m + tm;
+            __syncthreads();   // every wave has read the last stage: the stage buffers become the waves' staging slices
+            if (a.act == 0) gemm_epilogue_handoff_lines<0, MI, NI>(acc, Ly.bias + n0, Ct, Ly.ldc, wave, wave / GEMM_WN, wave % GEMM_WN, lane, smem);
+            else if (a.act == 1) gemm_epilogue_handoff_lines<1, MI, NI>(acc, Ly.bias + n0, Ct, Ly.ldc, wave, wave / GEMM_WN, wave % GEMM_WN, lane, smem);
+            else gemm_epilogue_handoff_lines<2, MI, NI>(acc, Ly.bias + n0, Ct, Ly.ldc, wave, wave / GEMM_WN, wave % GEMM_WN, lane, smem);
+            if (tid == 0) publish = l * a.tiles_m + tm;
         } else {
-            constexpr int BN = OUT_WIDE ? 384 : 256, BK = OUT_WIDE ? 16 : 32;
+            // 192-wide tiles where the class count pads to a multiple of 384 (1909 -> 1920 = 10 x 192): the last items of the launch are
+            // output tiles, and the ragged end of the launch costs about half an item per workgroup -- 0.19 ms items instead of 0.37
+            constexpr int BN = OUT_192 ? 192 : 256, BK = 32;
             constexpr int MI = GEMM_BM / GEMM_WM / 32, NI = BN / GEMM_WN / 32;
             f32x16 acc[MI][NI];
             const int n0 = tn * BN;
-            gemm_tile_products<BN, BK, 16, false>(A, lda, Ly.W, Ly.ldw, m0, n0, Ly.nk, 0, 0, smem, acc);
+            gemm_tile_products<BN, BK, 16, false>(A, lda, Ly.W, Ly.ldw, m0, n0, Ly.nk, 0, 0, smem, acc, hook);
             gemm_tile_epilogue<BN>(acc, Ly.bias, Ly.C, Ly.ldc, m0, n0, a.act, a.out_epi, a.out_alpha);   // plain stores: read by later launches only
-            publish = -1;
+        }
+    }
+    // every queue is dry: the last hidden tile this workgroup stored still has to be signalled
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        signal();
+        if (a.stamps) {
+            unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
+            o[0] = st_start; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = st_tiles; o[3] = st_wait; o[4] = st_waits; o[5] = st_stolen; o[6] = st_last;
+            o[7] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID, bits 0..3
         }
     }
 }
 
 hipError_t init_stack_kernel()
 {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_stack_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_256);
+    static_assert(GEMM_STACK_LDS >= GEMM_LDS_256 && GEMM_STACK_LDS >= GEMM_LDS_384, "the staging slices cover the products' stages");
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_stack_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_STACK_LDS);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)gemm_stack_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_256);
+    return hipFuncSetAttribute((const void*)gemm_stack_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_STACK_LDS);
 }
 
 hipError_t launch_gemm_stack(hipStream_t s, const GemmStackArgs& a, int out_n_pad)
 {
-    if (a.n_hidden < 1 || a.n_hidden > GEMM_STACK_MAX_HIDDEN || a.tiles_m <= 0 || a.n_items <= 0) return hipErrorInvalidValue;
-    const int grid = std::min(a.n_items, 256);   // one workgroup per CU
-    if (out_n_pad % 256 == 0) hipLaunchKernelGGL(gemm_stack_kernel<false>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_256, s, a);
-    else if (out_n_pad % 384 == 0) hipLaunchKernelGGL(gemm_stack_kernel<true>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_256, s, a);
+    if (a.n_hidden < 1 || a.n_hidden > GEMM_STACK_MAX_HIDDEN || a.tiles_m <= 0 || a.cum_total <= 0) return hipErrorInvalidValue;
+    const int grid = (int)std::min<long long>((long long)a.tiles_m * a.cum_total, 256);   // one workgroup per CU
+    if (out_n_pad % 256 == 0) hipLaunchKernelGGL(gemm_stack_kernel<false>, dim3(grid), dim3(GEMM_THREADS), GEMM_STACK_LDS, s, a);
+    else if (out_n_pad % 192 == 0) hipLaunchKernelGGL(gemm_stack_kernel<true>, dim3(grid), dim3(GEMM_THREADS), GEMM_STACK_LDS, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
