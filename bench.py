@@ -212,8 +212,7 @@ def secondary_records(eng, ft, params, layers, x, steps):
     k = max(steps, 5)
     whole = FLOPS_PER_FRAME["4x1024"] * n57 * k / wall / 1e12
     out["n57919"] = {"value": n57 * k / wall, "unit": "frames/s", "ms_per_step": wall * 1e3 / k, "frames": n57,
-                     "roofline": {"bound": "mfma", "kernel": "whole step (at this size the rows go down the layers as two chains on two streams, so the GEMM launches overlap "
-                                  "and their summed durations exceed the wall time: the fraction is flop / wall time / peak)",
+                     "roofline": {"bound": "mfma", "kernel": "whole step (splice + transform, the Linear stack, log-softmax): the fraction is flop / wall time / peak",
                                   "achieved": whole, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": whole / PEAK_F32_MFMA_TFLOPS},
                      "gemm_launch_ms_sum_per_step": sum(prof[k_][1] for k_ in ("gemm_hidden", "gemm_out", "gemm_stack") if k_ in prof) / k}
     p.close()
@@ -313,7 +312,10 @@ def main():
         value = frames_total / wall
         flops_step = FLOPS_PER_FRAME[args.model] * args.frames
         gemm_calls, gemm_ms, achieved = gemm_roofline(prof, flops_step * args.steps)
-        traffic, traffic_src = pmc_traffic() if (args.model == "4x1024" and args.frames == 196608) else (None, None)
+        stack = "gemm_stack" in prof   # the whole Linear stack as one work-queue launch (the default form)
+        launches_per_step = gemm_calls // max(args.steps, 1)
+        traffic, traffic_src = (pmc_traffic("am::gemm_stack_kernel" if stack else "am::gemm_nt_f32_kernel")
+                                if (args.model == "4x1024" and args.frames == 196608) else (None, None))
         out = {
             "metric": "frames/sec (posterior compute), %s ReLU DNN, fbank40 splice+-5, fp32" % args.model,
             "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -323,11 +325,12 @@ def main():
                                    "splice+transform+forward+log-softmax device-resident" % (args.model, args.model, args.frames),
                        "frames_per_gpu": args.frames, "parallelism": "frame shards, no collective"},
             "device_ms_per_step": dev_ms / args.steps,
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_f32_kernel (all Linear layers: %d launches/step)" % (gemm_calls // max(args.steps, 1)),
+            "roofline": {"bound": "mfma", "kernel": ("gemm_stack_kernel (all Linear layers of the network as one work-queue launch: %d launch/step)" if stack else
+                                                     "gemm_nt_f32_kernel (all Linear layers: %d launches/step)") % launches_per_step,
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC, %s)" % traffic_src if traffic else None,
-                         "algorithmic_bytes_per_launch": (args.frames * 4 * (440 + 4 * 1024 + 4 * 1024 + 1909) + 4 * (440 * 1024 + 3 * 1024 * 1024 + 1024 * 1909)) / 5.0 if args.model == "4x1024" else None,
+                         "algorithmic_bytes_per_launch": (args.frames * 4 * (440 + 4 * 1024 + 4 * 1024 + 1909) + 4 * (440 * 1024 + 3 * 1024 * 1024 + 1024 * 1909)) / float(max(launches_per_step, 1)) if args.model == "4x1024" else None,
                          "avg_launch_ms": gemm_ms / gemm_calls if gemm_calls else None,
                          "measured": "HIP events around every launch on the engine's compute stream, in a second loop of the same K steps (the headline loop carries no events)"},
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},
