@@ -166,7 +166,12 @@ int am_pipeline_set_normalise(am_pipeline* p, int on);
  * compute stream (asynchronous); am_ff_download copies y [n, C] back and synchronises.
  * am_forward_ff = upload, then the device path in 16,384-row chunks (AM_FF_PIPE_ROWS) with the download of chunk c overlapping the
  * compute of chunk c+1 on a separate stream (same results).  Replaces the FF branch of predict (predict_folds.py:69-94) and of
- * evaluateModelTestTri (evaluateModelForTest.py:98-112). */
+ * evaluateModelTestTri (evaluateModelForTest.py:98-112).
+ * Kernel form: networks whose hidden widths pad to multiples of 256 (<= 8 hidden layers) run their whole Linear stack as ONE
+ * launch, a work queue over (layer, row tile, column tile) with write-through hand-off of the hidden activations between
+ * workgroups (gemm_stack_kernel); everything else, and AM_FF_STACK=0 in the environment, one launch per layer.
+ * Same bits either way.  The inter-workgroup waits are bounded: a launch that gives up is repeated on the per-layer launches
+ * inside am_ff_download / am_forward_ff / am_decode_pipeline (counted by am_lstm_fallback_count), never a wrong result. */
 int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, int64_t n, int halo_lo, int halo_hi);
 int am_ff_run(am_pipeline* p);
 int am_ff_download(am_pipeline* p, float* y);
@@ -202,8 +207,9 @@ int am_lstm_stamps(am_pipeline* p, unsigned long long* out, int64_t capacity, in
  * (100 MHz ticks), tiles computed, ticks spent in dependency waits, number of waits, tiles taken from another XCD's queue, start
  * of its last tile, XCC id.  out: [256][8]. */
 int am_ff_stack_stamps(am_pipeline* p, unsigned long long* out);
-/* How often, in this process, a persistent recurrent launch gave up on a bounded wait and the pass was repeated on the per-step
- * kernels (0 in a healthy run; the tests and the randomised sweep assert it). */
+/* How often, in this process, a persistent launch (the recurrent kernel, or the single-launch Linear stack) gave up on a bounded
+ * wait and the pass was repeated on the per-step / per-layer kernels (0 in a healthy run; the tests and the randomised sweep
+ * assert it). */
 int am_lstm_fallback_count(void);
 
 /* number of frames / classes of the resident output (after *_upload) */
