@@ -203,9 +203,10 @@ int am_forward_lstm(am_pipeline* p, const float* x, const float* ivec, const int
  * GPU's 100 MHz counter per (row group, time step): step start, after the upward wait / product, after the lateral wait /
  * product, stores issued, published.  out: [n_groups][n_steps][8] or NULL to query the sizes. */
 int am_lstm_stamps(am_pipeline* p, unsigned long long* out, int64_t capacity, int* n_groups, int* n_steps);
-/* Diagnostic (AM_FF_STAMPS=1): per workgroup of the last single-launch Linear stack (gemm_stack_kernel) 8 words: start and end
+/* Diagnostic (AM_FF_STAMPS=1): per workgroup of the last single-launch Linear stack (gemm_stack_kernel) 16 words: start and end
  * (100 MHz ticks), tiles computed, ticks spent in dependency waits, number of waits, tiles taken from another XCD's queue, start
- * of its last tile, XCC id.  out: [256][8]. */
+ * of its last tile, XCC id; then ticks summed over its tiles: item pull + dependency check, cold start (to the first stage
+ * barrier), the product loop, the epilogue; 4 unused.  out: [256][16]. */
 int am_ff_stack_stamps(am_pipeline* p, unsigned long long* out);
 /* How often, in this process, a persistent launch (the recurrent kernel, or the single-launch Linear stack) gave up on a bounded
  * wait and the pass was repeated on the per-step / per-layer kernels (0 in a healthy run; the tests and the randomised sweep

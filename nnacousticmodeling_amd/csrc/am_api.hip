@@ -1075,8 +1075,8 @@ static int ff_member_forward_stack(am_pipeline* p, int mi, int64_t rows_pad, flo
     a.abort_flag = (int*)sync; a.queues = (int*)sync + FF_SYNC_QUEUES; a.done = sync + FF_SYNC_DONE; a.cum_total = item;
     a.test_extra = env_int("AM_FF_TEST_TIMEOUT", 0) ? 1 : 0;
     if (env_int("AM_FF_STAMPS", 0)) {   // diagnostic timeline of this launch (am_ff_stack_stamps)
-        AM_TRY(p->d_stamps.ensure(sizeof(unsigned long long) * 8 * 256));
-        HIP_TRY(hipMemsetAsync(p->d_stamps.p, 0, sizeof(unsigned long long) * 8 * 256, e->stream));
+        AM_TRY(p->d_stamps.ensure(sizeof(unsigned long long) * 16 * 256));
+        HIP_TRY(hipMemsetAsync(p->d_stamps.p, 0, sizeof(unsigned long long) * 16 * 256, e->stream));
         a.stamps = p->d_stamps.as<unsigned long long>();
     }   // test hook: arrival targets nobody reaches -> the waits must time out
     HIP_TRY(hipMemsetAsync(sync + FF_SYNC_QUEUES, 0, sizeof(unsigned) * (FF_SYNC_DONE - FF_SYNC_QUEUES + (size_t)m->n_layers * tiles_m), e->stream));
@@ -1306,7 +1306,7 @@ extern "C" int am_ff_stack_stamps(am_pipeline* p, unsigned long long* out)
     if (!p || !out || p->mode != 1 || !p->used_stack || !p->d_stamps.p) return fail(AM_EINVAL, "am_ff_stack_stamps: no stamped single-launch pass (AM_FF_STAMPS=1, am_ff_run)");
     HIP_TRY(hipSetDevice(p->e->device));
     AM_TRY(sync_all(p->e));
-    HIP_TRY(hipMemcpy(out, p->d_stamps.p, sizeof(unsigned long long) * 8 * 256, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, p->d_stamps.p, sizeof(unsigned long long) * 16 * 256, hipMemcpyDeviceToHost));
     return AM_OK;
 }
 

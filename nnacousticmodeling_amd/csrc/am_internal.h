@@ -64,7 +64,7 @@ struct GemmStackArgs {
     int* abort_flag;             // set when a wait ran into its bound (the pass is then invalid)
     int cum_total;               // column tiles of all layers: queue x has (row tiles of x) * cum_total items
     int test_extra;              // added to every wait's target (0; the give-up test sets 1)
-    unsigned long long* stamps;  // diagnostic [workgroups][8] or nullptr: start, end (100 MHz ticks), tiles, ticks waited, waits, stolen tiles, last tile's start, XCC id
+    unsigned long long* stamps;  // diagnostic [workgroups][16] or nullptr (am_ff_stack_stamps): selects the STAMPS instantiation
 };
 hipError_t launch_gemm_stack(hipStream_t s, const GemmStackArgs& a, int out_n_pad);
 

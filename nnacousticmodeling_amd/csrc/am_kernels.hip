@@ -374,7 +374,7 @@ __device__ __forceinline__ void gemm_epilogue_handoff_lines(const f32x16 (&acc)[
     }
 }
 
-template <bool OUT_192>
+template <bool OUT_192, bool STAMPS>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_stack_kernel(const GemmStackArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -385,11 +385,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_stack_kernel(const GemmS
     int publish = -1;                                  // counter of the hidden tile this workgroup stored last, not yet signalled
     int cur_q = blockIdx.x & 7, stolen = 0;            // the queue it pulls from (its XCD's own until that runs dry)
     int pulled = tid == 0 ? atomicAdd(a.queues + cur_q * GEMM_STACK_QSTRIDE, 1) : 0;
-    unsigned long long st_start = 0, st_wait = 0, st_last = 0; int st_tiles = 0, st_stolen = 0, st_waits = 0;   // diagnostic timeline (a.stamps)
-    if (a.stamps && tid == 0) st_start = __builtin_amdgcn_s_memrealtime();
+    // diagnostic timeline (the STAMPS instantiation only; a.stamps): per workgroup its start / end, tiles, waits, and where a tile's time goes
+    unsigned long long st_start = 0, st_wait = 0, st_last = 0, st_t = 0, st_ph[4] = {0, 0, 0, 0}; int st_tiles = 0, st_stolen = 0, st_waits = 0;
+    auto phase = [&](int k) { if (STAMPS && tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); if (k >= 0) st_ph[k] += now - st_t; st_t = now; } };
+    if (STAMPS && tid == 0) st_start = __builtin_amdgcn_s_memrealtime();
     auto rows_of = [&](int q) { return a.tiles_m > q ? (a.tiles_m - q + 7) >> 3 : 0; };   // row tiles of queue q: q, q + 8, ...
     auto signal = [&] { if (publish >= 0) { __hip_atomic_fetch_add(a.done + publish, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); publish = -1; } };
     for (;;) {
+        phase(-1);
         __syncthreads();                               // the previous iteration's reads of s_* are done
         if (tid == 0) {
             while (stolen < 8 && pulled >= rows_of(cur_q) * a.cum_total) {   // this queue is dry: move on to the next XCD's
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_stack_kernel(const GemmS
                 if (tid == 0) {
                     signal();
                     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                    ++st_waits;
+                    if (STAMPS) ++st_waits;
                     int it = 0;
                     while (ld_agent_u32(c) < target) {
                         __builtin_amdgcn_s_sleep(4);
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_stack_kernel(const GemmS
                             break;
                         }
                     }
-                    if (a.stamps) st_wait += __builtin_amdgcn_s_memrealtime() - t0;
+                    if (STAMPS) st_wait += __builtin_amdgcn_s_memrealtime() - t0;
                 }
                 __syncthreads();
                 if (s_abort) return;
@@ -442,16 +445,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_stack_kernel(const GemmS
         }
         // behind the first stage's barrier every wave has drained its stores of the previous tile: signal that tile there, and
         // pull the next item (its number is needed a whole tile later)
-        auto hook = [&] { if (tid == 0) { signal(); pulled = atomicAdd(a.queues + cur_q * GEMM_STACK_QSTRIDE, 1); } };
+        auto hook = [&] { if (tid == 0) { phase(1); signal(); pulled = atomicAdd(a.queues + cur_q * GEMM_STACK_QSTRIDE, 1); } };
         const float* A = l > 0 ? a.L[l - 1].C : a.A0;
         const int lda = l > 0 ? a.L[l - 1].ldc : a.lda0;
         const int m0 = tm * GEMM_BM;
-        if (a.stamps && tid == 0) { ++st_tiles; st_stolen += stolen > 0; st_last = __builtin_amdgcn_s_memrealtime(); }
+        if (STAMPS && tid == 0) { ++st_tiles; st_stolen += stolen > 0; st_last = __builtin_amdgcn_s_memrealtime(); }
+        phase(0);   // pull + decode + dependency check
         if (l < a.n_hidden) {
             constexpr int MI = GEMM_BM / GEMM_WM / 32, NI = 256 / GEMM_WN / 32;
             f32x16 acc[MI][NI];
             const int n0 = tn * 256;
             gemm_tile_products<256, 32, 16, true>(A, lda, Ly.W, Ly.ldw, m0, n0, Ly.nk, 0, 0, smem, acc, hook);
+            phase(2);   // first barrier -> last MFMA
             const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
             float* Ct = Ly.C + (size_t)m0 * Ly.ldc + n0;
             __syncthreads();   // every wave has read the last stage: the stage buffers become the waves' staging slices
@@ -459,6 +464,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_stack_kernel(const GemmS
             else if (a.act == 1) gemm_epilogue_handoff_lines<1, MI, NI>(acc, Ly.bias + n0, Ct, Ly.ldc, wave, wave / GEMM_WN, wave % GEMM_WN, lane, smem);
             else gemm_epilogue_handoff_lines<2, MI, NI>(acc, Ly.bias + n0, Ct, Ly.ldc, wave, wave / GEMM_WN, wave % GEMM_WN, lane, smem);
             if (tid == 0) publish = l * a.tiles_m + tm;
+            phase(3);   // epilogue
         } else {
             // 192-wide tiles where the class count pads to a multiple of 384 (1909 -> 1920 = 10 x 192): the last items of the launch are
             // output tiles, and the ragged end of the launch costs about half an item per workgroup -- 0.19 ms items instead of 0.37
@@ -467,7 +473,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_stack_kernel(const GemmS
             f32x16 acc[MI][NI];
             const int n0 = tn * BN;
             gemm_tile_products<BN, BK, 16, false>(A, lda, Ly.W, Ly.ldw, m0, n0, Ly.nk, 0, 0, smem, acc, hook);
+            phase(2);
             gemm_tile_epilogue<BN>(acc, Ly.bias, Ly.C, Ly.ldc, m0, n0, a.act, a.out_epi, a.out_alpha);   // plain stores: read by later launches only
+            phase(3);
         }
     }
     // every queue is dry: the last hidden tile this workgroup stored still has to be signalled
@@ -475,8 +483,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_stack_kernel(const GemmS
     __syncthreads();
     if (tid == 0) {
         signal();
-        if (a.stamps) {
-            unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
+        if (STAMPS) {
+            unsigned long long* o = a.stamps + (size_t)blockIdx.x * 16;
+            o[8] = st_ph[0]; o[9] = st_ph[1]; o[10] = st_ph[2]; o[11] = st_ph[3];
             o[0] = st_start; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = st_tiles; o[3] = st_wait; o[4] = st_waits; o[5] = st_stolen; o[6] = st_last;
             o[7] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID, bits 0..3
         }
@@ -486,18 +495,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_stack_kernel(const GemmS
 hipError_t init_stack_kernel()
 {
     static_assert(GEMM_STACK_LDS >= GEMM_LDS_256 && GEMM_STACK_LDS >= GEMM_LDS_384, "the staging slices cover the products' stages");
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_stack_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_STACK_LDS);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)gemm_stack_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_STACK_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_stack_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_STACK_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_stack_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_STACK_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_stack_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_STACK_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_stack_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_STACK_LDS);
+    return e;
 }
 
 hipError_t launch_gemm_stack(hipStream_t s, const GemmStackArgs& a, int out_n_pad)
 {
     if (a.n_hidden < 1 || a.n_hidden > GEMM_STACK_MAX_HIDDEN || a.tiles_m <= 0 || a.cum_total <= 0) return hipErrorInvalidValue;
     const int grid = (int)std::min<long long>((long long)a.tiles_m * a.cum_total, 256);   // one workgroup per CU
-    if (out_n_pad % 256 == 0) hipLaunchKernelGGL(gemm_stack_kernel<false>, dim3(grid), dim3(GEMM_THREADS), GEMM_STACK_LDS, s, a);
-    else if (out_n_pad % 192 == 0) hipLaunchKernelGGL(gemm_stack_kernel<true>, dim3(grid), dim3(GEMM_THREADS), GEMM_STACK_LDS, s, a);
-    else return hipErrorInvalidValue;
+    const bool w192 = out_n_pad % 256 != 0;
+    if (w192 && out_n_pad % 192 != 0) return hipErrorInvalidValue;
+#define AM_STACK_LAUNCH(W, S) hipLaunchKernelGGL((gemm_stack_kernel<W, S>), dim3(grid), dim3(GEMM_THREADS), GEMM_STACK_LDS, s, a)
+    if (a.stamps) { if (w192) AM_STACK_LAUNCH(true, true); else AM_STACK_LAUNCH(false, true); }
+    else if (w192) AM_STACK_LAUNCH(true, false);
+    else AM_STACK_LAUNCH(false, false);
+#undef AM_STACK_LAUNCH
     return hipGetLastError();
 }
 

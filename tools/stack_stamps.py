@@ -34,7 +34,7 @@ def main():
     for _ in range(3):
         p.ff_run()
     eng.synchronize()
-    st = np.zeros((256, 8), dtype=np.uint64)
+    st = np.zeros((256, 16), dtype=np.uint64)
     check(p._lib.am_ff_stack_stamps(p._h, st.ctypes.data_as(C.c_void_p)))
     st = st.astype(np.int64)
     live = st[:, 1] > 0
@@ -48,6 +48,8 @@ def main():
     print("tiles taken from another XCD's queue: %d" % st[live, 5].sum())
     idle = (end[live].max() - end[live]).sum() / live.sum()
     print("mean idle tail per workgroup: %.1f us (%.1f %% of the span)" % (idle, 100.0 * idle / end[live].max()))
+    ph = st[live, 8:12].sum(axis=0) / 100.0 / max(st[live, 2].sum(), 1)
+    print("per tile (mean over all tiles): pull + dependency check %.2f us, cold start %.2f us, product loop %.2f us, epilogue %.2f us" % tuple(ph))
     for x_ in range(8):
         sel = live & (st[:, 7] == x_)
         if sel.any():
