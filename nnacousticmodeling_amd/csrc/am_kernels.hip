@@ -313,7 +313,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g)
 //
 // Why: a layer launched on its own runs in whole rounds of 256 tiles -- 57,919 rows x 1024 = 908 tiles = 3.55 rounds, run as
 // 4 -- and every launch ends in a ragged tail.  Row tile r of layer l+1 needs only row tile r of layer l, so here the 256
-// resident workgroups pull items from ONE counter, layer-major, and the tail of layer l runs beside the head of layer l+1:
+// resident workgroups pull items from per-XCD counters, layer-major, and the tail of layer l runs beside the head of layer l+1:
 // one partial round per network instead of one per layer.
 //   item  = atomicAdd(queue of this XCD)   (eight queues: queue x holds the row tiles x, x + 8, ...; layer-major, column tile
 //                                           fastest, so the workgroups of an XCD share A panels in its L2; a dry queue -> the next XCD's)
