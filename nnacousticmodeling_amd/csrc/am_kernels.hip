@@ -1810,9 +1810,28 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_kernel(const LstmPersistA
 }
 
 
+// The persistent kernel needs all its workgroups resident at once.  A build of it that spills even one register needs scratch
+// memory, and the FIRST launch of a scratch-using kernel in a process does not get them all resident (measured with a
+// 2-VGPR spill: the first pass of every process ran into the 2-s bound and fell back; later launches were fine).  So the
+// form is only offered when the compiled kernel has no private segment -- a toolchain that starts spilling loses speed, not
+// two seconds per process.
+static bool lstm_persist_scratch_free(int U_pad)
+{
+    static int state[2] = {-1, -1};
+    int& st = state[U_pad == 512 ? 0 : 1];
+    if (st < 0) {
+        hipFuncAttributes at{};
+        const hipError_t e = U_pad == 512 ? hipFuncGetAttributes(&at, (const void*)lstm_persist_kernel<4>) : hipFuncGetAttributes(&at, (const void*)lstm_persist_kernel<2>);
+        st = (e == hipSuccess && at.localSizeBytes == 0) ? 1 : 0;
+        if (!st) fprintf(stderr, "libamfwd: the persistent recurrent kernel of this build uses scratch memory (%zu B per lane); staying on the per-step kernels\n", (size_t)at.localSizeBytes);
+    }
+    return st == 1;
+}
+
 int lstm_persist_capacity(int U_pad, int n_layers)
 {
     if ((U_pad != 256 && U_pad != 512) || n_layers < 1 || n_layers > LSTM_MAX_LAYERS) return 0;
+    if (!lstm_persist_scratch_free(U_pad)) return 0;
     const int nb = U_pad / LSTM_KB, budget = 256 / (U_pad / 16);
     int tiles = 0;
     for (int t0 = 1; t0 <= 4096; ++t0) {
