@@ -131,3 +131,38 @@ def test_stack_gives_up_and_falls_back(engine, real_ft_path, monkeypatch, capfd)
     y, prof = _stack_launches(engine, p, x)      # stays on the per-layer launches after a give-up
     assert "gemm_stack" not in prof and np.array_equal(y, good)
     p.close()
+
+
+def test_stack_launches_competing_for_the_gpu(real_ft_path, monkeypatch):
+    """Two engines on the same GPU, driven from two threads: their single-launch stacks compete for the CUs, so each launch runs
+    with a changing number of resident workgroups and uneven timing -- the hand-off of the hidden activations must not care
+    (the queue needs no co-residency).  Every pass must reproduce, bit for bit, what the same pipeline computed alone."""
+    import threading
+    from nnacousticmodeling_amd import _lib
+    from nnacousticmodeling_amd.engine import Engine
+    monkeypatch.setenv("AM_FF_STACK", "1")
+    ft = orc.load_kaldi_feature_transform(real_ft_path)
+    jobs = []
+    for seed, (layers, units, n) in enumerate(((4, 1024, 30011), (3, 512, 9001))):
+        rng = np.random.default_rng(100 + seed)
+        eng = Engine(0)
+        params = orc.make_mlp_params(rng, 440, units, layers, 1909)
+        x = rng.standard_normal((n, 40)).astype(np.float32)
+        p = _pipe(eng, [(layers, params)], ft, ft["shifts"])
+        jobs.append({"eng": eng, "p": p, "x": x, "alone": _resident(p, x), "bad": 0})
+    before = _lib.load().am_lstm_fallback_count()
+
+    def work(job, reps):
+        for _ in range(reps):
+            if not np.array_equal(_resident(job["p"], job["x"]), job["alone"]):
+                job["bad"] += 1
+
+    threads = [threading.Thread(target=work, args=(jobs[0], 12)), threading.Thread(target=work, args=(jobs[1], 40))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert [j["bad"] for j in jobs] == [0, 0]
+    assert _lib.load().am_lstm_fallback_count() == before
+    for j in jobs:
+        j["p"].close()
