@@ -136,7 +136,76 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_var(const float* __re
 #pragma unroll
         for (int t = 0; t < TS; ++t) { mma(fav, fbv); asm volatile("" : "+v"(fav[0]), "+v"(fbv[0])); }
     };
-    if constexpr (ORDER == 3) {
+    if constexpr (ORDER == 4) {
+        // PING-PONG: the two waves of a SIMD alternate.  Waves 0..3 ("A") multiply in even phases and fetch in odd ones, waves 4..7
+        // ("B") the other way round; a phase = one 8-k sub-step (32 MFMAs) for the multiplying half, and for the fetching half: the
+        // LDS fragment reads of its next sub-step + half of a stage's LDS-DMA requests (stage s+3 of a 4-stage ring) + its waits.
+        // One s_barrier between phases.  The matrix pipe always has one wave with operands in registers; LDS latency, the
+        // DMA issue and the waits of one half hide behind the MFMAs of the other.
+        // MEASURED (round 2, M=196608 N=K=1024): 129.9 TF/s against 143.0 for the product's order 2 -- a barrier every 2,048 cycles
+        // makes every SIMD wait for the slowest multiplying wave eight times as often; the two waves of a SIMD interleave well
+        // enough on their own.  Kept for the record.
+        static_assert(STAGES == 4 && TS == 2 && NW == 8 && LOADS % 2 == 0, "ping-pong: 4 stages of two sub-steps, 8 waves");
+        const bool grpB = wave >= NW / 2;
+        auto issue_piece = [&](int st, int l) {
+            const int kt = st < nk ? st : nk - 1;            // past the end: re-fetch the last stage into a buffer nobody reads
+            char* base = smem + (st & 3) * STAGE_BYTES;
+            const int k0 = kt * BK;
+            if (l < A_PER_WAVE) __builtin_amdgcn_global_load_lds(GP(ga[l] + k0), LP(base + (l * NW + wave) * 1024), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds(GP(gw[l - A_PER_WAVE] + k0), LP(base + BM * BK * 4 + ((l - A_PER_WAVE) * NW + wave) * 1024), 16, 0, 0);
+        };
+#pragma unroll
+        for (int st = 0; st < 3; ++st)
+#pragma unroll
+            for (int l = 0; l < LOADS; ++l) issue_piece(st, l);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        f32x4 av[MI], bv[NI];
+        const int nu = nk * TS;
+        auto fetch = [&](int u) {        // the fetching half's phase for sub-step u
+            const int st = u >> 1, t = u & 1;
+            const f32x4* a4 = (const f32x4*)(smem + (st & 3) * STAGE_BYTES);
+            const f32x4* w4 = (const f32x4*)(smem + (st & 3) * STAGE_BYTES + BM * BK * 4);
+            load_frag(a4, w4, t, av, bv);
+#pragma unroll
+            for (int l = 0; l < LOADS / 2; ++l) issue_piece(st + 3, t * (LOADS / 2) + l);
+            if (t == 1) wait_vmcnt<2 * LOADS>();     // this wave's pieces of stage st+1 (first read in its next fetch phase) have landed
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) asm volatile("" : "+v"(av[mi]));   // fragments complete before the barrier
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) asm volatile("" : "+v"(bv[ni]));
+        };
+        auto multiply = [&] {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (!grpB) {
+            fetch(0);
+            __builtin_amdgcn_s_barrier();
+            for (int u = 0; u < nu; ++u) {
+                multiply();
+                __builtin_amdgcn_s_barrier();
+                if (u + 1 < nu) fetch(u + 1);
+                __builtin_amdgcn_s_barrier();
+            }
+        } else {
+            __builtin_amdgcn_s_barrier();
+            for (int u = 0; u < nu; ++u) {
+                fetch(u);
+                __builtin_amdgcn_s_barrier();
+                multiply();
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        wait_vmcnt<0>();
+    } else if constexpr (ORDER == 3) {
         // order 2 (LDS-DMA issue interleaved between MFMA groups) + software pipelining across the barrier: the last
         // 8-k sub-step of stage kt is multiplied AFTER the barrier that publishes stage kt+1, covering the latency of the
         // first fragment reads of the new stage.
@@ -318,6 +387,7 @@ int main(int argc, char** argv)
         {"v26 256x256x32 s2 4x2 w2 order2 (product)", launch_var<256, 256, 32, 2, 4, 2, 2, 2, 0, 0>},
         {"v40 256x256x32 s2 4x2 w2 order3 (pipelined across the barrier)", launch_var<256, 256, 32, 2, 4, 2, 2, 3, 0, 0>},
         {"v15 256x256x32 s2 4x2 w2 order0", launch_var<256, 256, 32, 2, 4, 2, 2, 0, 0, 0>},
+        {"v50 256x256x16 s4 4x2 w2 order4 (ping-pong)", launch_var<256, 256, 16, 4, 4, 2, 2, 4, 0, 0>},
     };
     if (M % 256) { printf("M must be a multiple of 256\n"); return 1; }
 
