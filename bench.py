@@ -215,6 +215,9 @@ def secondary_records(eng, ft, params, layers, x, steps):
                      "roofline": {"bound": "mfma", "kernel": "whole step (splice + transform, the Linear stack, log-softmax): the fraction is flop / wall time / peak",
                                   "achieved": whole, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": whole / PEAK_F32_MFMA_TFLOPS},
                      "gemm_launch_ms_sum_per_step": sum(prof[k_][1] for k_ in ("gemm_hidden", "gemm_out", "gemm_stack") if k_ in prof) / k}
+    _, gms, gach = gemm_roofline(prof, FLOPS_PER_FRAME["4x1024"] * n57 * k)
+    out["n57919"]["roofline_gemm"] = {"bound": "mfma", "kernel": "the Linear layers' launches alone (gemm_stack_kernel: one launch per step), as for the headline record",
+                                      "achieved": gach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": gach / PEAK_F32_MFMA_TFLOPS if gach else None}
     p.close()
     m4.close()
     # (iii) BASELINE configs[2]: 6x2048 on 440 spliced + 100 i-vector columns
