@@ -182,7 +182,7 @@ def gemm_roofline(prof, flops_total):
 
 def secondary_records(eng, ft, params, layers, x, steps):
     """The other BASELINE.json configurations and SURVEY.md 8d figures, one GPU, outside the headline `value`:
-    end to end (host array in, pinned host array out), the core-test-like size, 6x2048 + i-vectors, the 3x512 LSTM."""
+    end to end (host array in, pinned host array out), the core-test-like size, 6x2048 + i-vectors, the 3x512 LSTM, the 10-member ensemble."""
     from nnacousticmodeling_amd.engine import Model, Pipeline
     from nnacousticmodeling_amd.kaldi_ft import loadKaldiFeatureTransform, select_centre_frame
     from nnacousticmodeling_amd.synthetic import make_lstm_params, make_mlp_params, make_offsets
@@ -261,6 +261,26 @@ def secondary_records(eng, ft, params, layers, x, steps):
                          "kernels_ms_per_pass": {k_: v[1] / kl for k_, v in prof.items()}}
     p.close()
     ml.close()
+    # (v) BASELINE configs[4]: 10 fold members (4x1024 each), logits averaged on the device (evaluate.py:35-51) -- one GPU's share;
+    # on a node the folds x utterances shard over the GPUs with no collective (sharding.py)
+    rng = np.random.default_rng(SEED + 4)
+    members = [Model(eng, "ff", layers, make_mlp_params(rng, 440, 1024, layers, 1909)) for _ in range(10)]
+    p = Pipeline(eng)
+    p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+    p.set_members(members)
+    p.ff_upload(x[:n57], None, n57, 0, 0)
+    ke = max(steps // 6, 3)
+    wall, _, prof = timed_runs(eng, p.ff_run, ke, 1)
+    whole = 10 * FLOPS_PER_FRAME["4x1024"] * n57 * ke / wall / 1e12
+    _, _, gach = gemm_roofline(prof, 10 * FLOPS_PER_FRAME["4x1024"] * n57 * ke)
+    out["ensemble_10x4x1024"] = {"value": n57 * ke / wall, "unit": "frames/s", "ms_per_pass": wall * 1e3 / ke, "frames": n57, "members": 10,
+                                 "roofline": {"bound": "mfma", "kernel": "whole pass (10 stack launches + combine + log-softmax)", "achieved": whole,
+                                              "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": whole / PEAK_F32_MFMA_TFLOPS},
+                                 "roofline_gemm": {"bound": "mfma", "achieved": gach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                                   "frac": gach / PEAK_F32_MFMA_TFLOPS if gach else None}}
+    p.close()
+    for m_ in members:
+        m_.close()
     return out
 
 
