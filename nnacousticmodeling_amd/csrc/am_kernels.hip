@@ -336,11 +336,15 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g)
 // Each wave stages 32 rows x 128 columns at a time in its own 17-KB slice (row stride 136 floats: conflict-free b128 writes).
 constexpr int GEMM_STACK_STAGE_LD = 136;
 constexpr int GEMM_STACK_LDS = (GEMM_WM * GEMM_WN) * 32 * GEMM_STACK_STAGE_LD * 4;   // 139,264 B >= the products' two stages
-template <int MODE, int MI, int NI>
+// MODE: 0 relu, 1 sigmoid, 2 tanh (hidden layers, stored write-through: AUX = 16); 5 accumulate into C (an ensemble's second and later
+// members: C = C + (acc + bias), plain loads and stores, AUX = 0 -- as whole lines the read-modify-write is 1.8 % of a 10-member
+// pass faster than gemm_epilogue's 4-byte accesses).  NI = 4 (256-wide tiles: a wave's rows are 512 B) or 3 (192-wide: 384 B).
+template <int MODE, int AUX, int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue_handoff_lines(const f32x16 (&acc)[MI][NI], const float* __restrict__ bias, float* __restrict__ Ctile, int ldc,
                                                             int wave, int wm, int wn, int lane, char* smem)
 {
-    static_assert(NI * 32 + 8 == GEMM_STACK_STAGE_LD, "stage row = the wave's 128 columns + pad");
+    constexpr int LD = NI * 32 + 8;                 // 136 / 104 floats: = 8 (mod 16), conflict-free b128 writes down a column of rows
+    static_assert(LD <= GEMM_STACK_STAGE_LD, "a wave's staging slice holds 32 rows");
     const int li = lane & 31, lh = lane >> 5;
     float* stage = (float*)smem + wave * (32 * GEMM_STACK_STAGE_LD);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Ctile, 0, 0x7fffffff, 0x00020000);
@@ -358,23 +362,32 @@ __device__ __forceinline__ void gemm_epilogue_handoff_lines(const f32x16 (&acc)[
                     float x = acc[mi][ni][4 * g + j] + bv[j];
                     if (MODE == 0) x = fmaxf(x, 0.0f);
                     else if (MODE == 1) x = am_sigmoid(x);
-                    else x = tanhf(x);
+                    else if (MODE == 2) x = tanhf(x);
                     v[j] = x;
                 }
-                *(f32x4*)(stage + li * GEMM_STACK_STAGE_LD + col) = v;
+                *(f32x4*)(stage + li * LD + col) = v;
             }
         }
+        // out as whole 128-B lines: 8 lanes per line, 8 lines per store instruction
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = 2 * i + lh;
-            const f32x4 v = *(const f32x4*)(stage + row * GEMM_STACK_STAGE_LD + 4 * li);
-            const unsigned off = (unsigned)(wm * (GEMM_BM / GEMM_WM) + mi * 32 + row) * (unsigned)ldc + (unsigned)(wn * (NI * 32) + 4 * li);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)(off * 4u), 0, 16 /* sc1 */);
+        for (int i = 0; i < 4 * NI; ++i) {
+            const int sgm = 8 * i + (lane >> 3);            // 128-B segment of the 32 x NI segments of this pass
+            const int row = sgm / NI, col = (sgm - row * NI) * 32 + 4 * (lane & 7);
+            f32x4 v = *(const f32x4*)(stage + row * LD + col);
+            const unsigned off = (unsigned)(wm * (GEMM_BM / GEMM_WM) + mi * 32 + row) * (unsigned)ldc + (unsigned)(wn * (NI * 32) + col);
+            if (MODE == 5) {
+                const f32x4 old = *(const f32x4*)(Ctile + off);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = old[j] + v[j];
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)(off * 4u), 0, AUX);
         }
     }
 }
 
-template <bool OUT_192, bool STAMPS>
+// OUT_ACCUM: the instantiation for an ensemble's second and later members (output epilogue C = C + ...): a kernel of its own so that
+// its extra tile code does not cost the single-network kernel registers (0.6 % on the headline when both lived in one kernel).
+template <bool OUT_192, bool STAMPS, bool OUT_ACCUM>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_stack_kernel(const GemmStackArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -460,9 +473,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_stack_kernel(const GemmS
             const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
             float* Ct = Ly.C + (size_t)m0 * Ly.ldc + n0;
             __syncthreads();   // every wave has read the last stage: the stage buffers become the waves' staging slices
-            if (a.act == 0) gemm_epilogue_handoff_lines<0, MI, NI>(acc, Ly.bias + n0, Ct, Ly.ldc, wave, wave / GEMM_WN, wave % GEMM_WN, lane, smem);
-            else if (a.act == 1) gemm_epilogue_handoff_lines<1, MI, NI>(acc, Ly.bias + n0, Ct, Ly.ldc, wave, wave / GEMM_WN, wave % GEMM_WN, lane, smem);
-            else gemm_epilogue_handoff_lines<2, MI, NI>(acc, Ly.bias + n0, Ct, Ly.ldc, wave, wave / GEMM_WN, wave % GEMM_WN, lane, smem);
+            if (a.act == 0) gemm_epilogue_handoff_lines<0, 16, MI, NI>(acc, Ly.bias + n0, Ct, Ly.ldc, wave, wave / GEMM_WN, wave % GEMM_WN, lane, smem);
+            else if (a.act == 1) gemm_epilogue_handoff_lines<1, 16, MI, NI>(acc, Ly.bias + n0, Ct, Ly.ldc, wave, wave / GEMM_WN, wave % GEMM_WN, lane, smem);
+            else gemm_epilogue_handoff_lines<2, 16, MI, NI>(acc, Ly.bias + n0, Ct, Ly.ldc, wave, wave / GEMM_WN, wave % GEMM_WN, lane, smem);
             if (tid == 0) publish = l * a.tiles_m + tm;
             phase(3);   // epilogue
         } else {
@@ -472,9 +485,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_stack_kernel(const GemmS
             constexpr int MI = GEMM_BM / GEMM_WM / 32, NI = BN / GEMM_WN / 32;
             f32x16 acc[MI][NI];
             const int n0 = tn * BN;
-            gemm_tile_products<BN, BK, 16, false>(A, lda, Ly.W, Ly.ldw, m0, n0, Ly.nk, 0, 0, smem, acc, hook);
-            phase(2);
-            gemm_tile_epilogue<BN>(acc, Ly.bias, Ly.C, Ly.ldc, m0, n0, a.act, a.out_epi, a.out_alpha);   // plain stores: read by later launches only
+            if (OUT_ACCUM) {   // an ensemble's later members: the read-modify-write of the running sum as whole lines
+                gemm_tile_products<BN, BK, 16, true>(A, lda, Ly.W, Ly.ldw, m0, n0, Ly.nk, 0, 0, smem, acc, hook);
+                phase(2);
+                const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+                __syncthreads();
+                gemm_epilogue_handoff_lines<5, 0, MI, NI>(acc, Ly.bias + n0, Ly.C + (size_t)m0 * Ly.ldc + n0, Ly.ldc, wave, wave / GEMM_WN, wave % GEMM_WN, lane, smem);
+            } else {
+                gemm_tile_products<BN, BK, 16, false>(A, lda, Ly.W, Ly.ldw, m0, n0, Ly.nk, 0, 0, smem, acc, hook);
+                phase(2);
+                gemm_tile_epilogue<BN>(acc, Ly.bias, Ly.C, Ly.ldc, m0, n0, a.act, a.out_epi, a.out_alpha);   // plain stores: read by later launches only
+            }
             phase(3);
         }
     }
@@ -495,10 +516,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_stack_kernel(const GemmS
 hipError_t init_stack_kernel()
 {
     static_assert(GEMM_STACK_LDS >= GEMM_LDS_256 && GEMM_STACK_LDS >= GEMM_LDS_384, "the staging slices cover the products' stages");
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_stack_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_STACK_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_stack_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_STACK_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_stack_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_STACK_LDS);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_stack_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_STACK_LDS);
+    hipError_t e = hipSuccess;
+#define AM_STACK_ATTR(W, S, C) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_stack_kernel<W, S, C>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_STACK_LDS)
+    AM_STACK_ATTR(false, false, false); AM_STACK_ATTR(true, false, false); AM_STACK_ATTR(false, false, true); AM_STACK_ATTR(true, false, true);
+    AM_STACK_ATTR(false, true, false); AM_STACK_ATTR(true, true, false);
+#undef AM_STACK_ATTR
     return e;
 }
 
@@ -508,10 +530,12 @@ hipError_t launch_gemm_stack(hipStream_t s, const GemmStackArgs& a, int out_n_pa
     const int grid = (int)std::min<long long>((long long)a.tiles_m * a.cum_total, 256);   // one workgroup per CU
     const bool w192 = out_n_pad % 256 != 0;
     if (w192 && out_n_pad % 192 != 0) return hipErrorInvalidValue;
-#define AM_STACK_LAUNCH(W, S) hipLaunchKernelGGL((gemm_stack_kernel<W, S>), dim3(grid), dim3(GEMM_THREADS), GEMM_STACK_LDS, s, a)
-    if (a.stamps) { if (w192) AM_STACK_LAUNCH(true, true); else AM_STACK_LAUNCH(false, true); }
-    else if (w192) AM_STACK_LAUNCH(true, false);
-    else AM_STACK_LAUNCH(false, false);
+#define AM_STACK_LAUNCH(W, S, C) hipLaunchKernelGGL((gemm_stack_kernel<W, S, C>), dim3(grid), dim3(GEMM_THREADS), GEMM_STACK_LDS, s, a)
+    const bool accum = a.out_epi == EPI_ACCUM;
+    if (a.stamps && !accum) { if (w192) AM_STACK_LAUNCH(true, true, false); else AM_STACK_LAUNCH(false, true, false); }
+    else if (accum) { if (w192) AM_STACK_LAUNCH(true, false, true); else AM_STACK_LAUNCH(false, false, true); }
+    else if (w192) AM_STACK_LAUNCH(true, false, false);
+    else AM_STACK_LAUNCH(false, false, false);
 #undef AM_STACK_LAUNCH
     return hipGetLastError();
 }
