@@ -1660,7 +1660,10 @@ static int lstm_enqueue(am_pipeline* p)
             Layer& L0 = m->L[0];
             GemmArgs g{};
             g.A = p->d_in.as<float>(); g.lda = m->in_pad; g.W = L0.W.as<float>(); g.ldw = L0.in_pad; g.bias = L0.b.as<float>();
-            g.C = p->d_G.as<float>(); g.ldc = L0.out_pad; g.M_pad = (int)rows_pad; g.N_pad = L0.out_pad; g.K_pad = L0.in_pad;
+            g.C = p->d_G.as<float>(); g.ldc = L0.out_pad; g.M_pad = (int)rows_pad; g.N_pad = L0.out_pad;
+            // the input plane is padded to 128 columns for the recurrent kernels' k batches; the columns past the real input are zeros on
+            // both sides, so the product stops at the GEMM's own k step (40 inputs: 64 instead of 128 -- half the launch, the same bits)
+            g.K_pad = std::min(L0.in_pad, (int)round_up(L0.in, GEMM_BK));
             g.epi = EPI_LINEAR; g.alpha = 1.f;
             AM_TRY(run_kernel(e, K_LSTM_UPWARD, [&] { return launch_gemm(e->stream, g); }));
         }

@@ -261,6 +261,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(
 
 constexpr int GEMM_LDS_256 = 2 * (GEMM_BM + 256) * 32 * 4;  // 128 KiB
 constexpr int GEMM_LDS_384 = 2 * (GEMM_BM + 384) * 16 * 4;  //  80 KiB
+constexpr int GEMM_LDS_192 = 2 * (GEMM_BM + 192) * 32 * 4;  // 112 KiB
 
 hipError_t init_split_kernels();
 hipError_t init_lstm_kernels();
@@ -280,6 +281,8 @@ hipError_t init_kernels()
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)gemm_nt_f32_kernel<384, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_384);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)gemm_nt_f32_kernel<192, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_192);
+    if (e != hipSuccess) return e;
     return init_stack_kernel();
 }
 
@@ -298,6 +301,13 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g)
         const int tiles_n = g.N_pad / 256, n_tiles = tiles_m * tiles_n;
         const int grid = g.queue ? std::min(n_tiles, 256) : n_tiles;     // work-queue mode: one block per CU slot is enough
         hipLaunchKernelGGL((gemm_nt_f32_kernel<256, 32>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_256, s,
+                           g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 32, g.act, g.epi, g.alpha, g.row_p, g.row_skip, g.queue, n_tiles);
+    } else if (g.N_pad % 192 == 0 && !getenv("AM_GEMM_384")) {
+        // 1909 classes -> 1920 = 10 x 192: half the tile of the 384-wide form (the round-1 choice, kept behind AM_GEMM_384 for A/B runs) --
+        // 96 accumulator registers instead of 192, no spills, and twice as many tiles to fill the last round of a launch with
+        const int tiles_n = g.N_pad / 192, n_tiles = tiles_m * tiles_n;
+        const int grid = g.queue ? std::min(n_tiles, 256) : n_tiles;
+        hipLaunchKernelGGL((gemm_nt_f32_kernel<192, 32>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_192, s,
                            g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 32, g.act, g.epi, g.alpha, g.row_p, g.row_skip, g.queue, n_tiles);
     } else if (g.N_pad % 384 == 0) {
         const int tiles_n = g.N_pad / 384, n_tiles = tiles_m * tiles_n;
