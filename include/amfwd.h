@@ -190,7 +190,8 @@ int am_forward_ff(am_pipeline* p, const float* x, const float* ivec, int64_t n, 
  * 512-unit layers) run as ONE persistent launch with the weights resident in registers (lstm_persist_kernel); every other
  * shape, and the GRU / MGRU / peephole cells, run one launch per time step of the (layer, time) wavefront.  Both forms give
  * the same bits.  The persistent kernel's inter-workgroup waits are bounded (2 s): if one ever times out, every workgroup leaves and
- * am_lstm_download / am_decode_pipeline repeat the pass on the per-step kernels (a line on stderr says so) -- never a hung GPU.
+ * am_lstm_download / am_decode_pipeline repeat the pass on the per-step kernels (a line on stderr says so) -- never a hung GPU --
+ * and the device stays on the per-step kernels for the rest of the process (am_lstm_persist_enabled / _reenable below).
  * Environment switches (measurement only): AM_LSTM_PERSIST=0 per-step kernels only; AM_LSTM_OVERLAP=0 no second-stream
  * overlap of the output layer with the recurrence's tail; AM_LSTM_GRAPH=0|1 hipGraph replay of the per-step form. */
 int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec, const int64_t* offsets, int n_utts, int timedelay);
@@ -212,6 +213,16 @@ int am_ff_stack_stamps(am_pipeline* p, unsigned long long* out);
  * wait and the pass was repeated on the per-step / per-layer kernels (0 in a healthy run; the tests and the randomised sweep
  * assert it). */
 int am_lstm_fallback_count(void);
+/* The persistent recurrent kernel needs all its workgroups resident at once.  Inside one process its launches on a device are
+ * chained (each waits for the previous one's completion, whichever engine launched it), and its grid is sized from the device's
+ * real CU count; what the library cannot see is another process holding CUs.  So a give-up is sticky: after the first one the
+ * device stays on the per-step kernels for the rest of the process (one 2-s stall, not one per upload).
+ * am_lstm_persist_enabled: 1 while uploads on `device` may still choose the persistent form (0 also with AM_LSTM_PERSIST=0);
+ * am_lstm_persist_reenable lifts the latch (tests; an operator who knows the card is free again).
+ * am_pipeline_recurrent_form: how many of the uploaded pipeline's members run as persistent launches. */
+int am_lstm_persist_enabled(int device);
+int am_lstm_persist_reenable(int device);
+int am_pipeline_recurrent_form(am_pipeline* p, int* n_persistent, int* n_members);
 
 /* number of frames / classes of the resident output (after *_upload) */
 int am_pipeline_output_shape(am_pipeline* p, int64_t* n, int* c);

@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstring>
 #include <dlfcn.h>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -73,6 +74,8 @@ struct am_engine {
     hipStream_t stream2 = nullptr;   // copy stream: D2H of chunk c overlaps the compute of chunk c+1 (am_forward_ff); second row chain
     hipStream_t chain[2] = {nullptr, nullptr};   // third / fourth row chain of a feed-forward chunk (ff_run_chunks)
     hipEvent_t s2_tail = nullptr;    // last work enqueued on stream2
+    hipEvent_t persist_done = nullptr;   // behind this engine's last persistent recurrent launch (PersistGate)
+    int n_cus = 0;                   // CUs of the device (hipDeviceProp_t::multiProcessorCount): grid sizes of the resident-workgroup kernels
     bool s2_dirty = false;
     int precision = AM_PRECISION_F32;  // AM_PRECISION_* for the feed-forward Linear layers
     DevBuf d_overflow;                 // int flag raised by split-f16 kernels when an activation does not fit f16
@@ -151,6 +154,7 @@ struct am_pipeline {
     std::vector<hipEvent_t> chunk_done;  // one-shot path: chunk c's posteriors are final (compute stream -> copy stream)
     // lstm
     DevBuf d_src, d_dst, d_G, d_H, d_c;   // d_H / d_c: one packed H plane and one cell-state array per layer
+    DevBuf d_cplane;                      // persistent form: the cell state as one time-major packed plane per layer, like d_H
     std::vector<int64_t> step_off;
     std::vector<int> n_active;
     int64_t n_packed = 0;
@@ -182,6 +186,23 @@ struct am_pipeline {
         results_valid = false;   // every caller is an upload or a configuration change
     }
 };
+
+// One persistent recurrent launch at a time per device.  lstm_persist_kernel needs ALL its workgroups resident (they wait for
+// each other); two of them launched side by side -- two engines on one card, PosteriorRunner([(0, 0), (0, 1)]) -- can each end up
+// partly resident, and then both run into the 2-s bound.  So every such launch first makes its stream wait (on the device) for
+// the previous one's completion event, whichever engine of this process launched it: a linear chain, no cycle, and other kernels
+// (the output layer beside the tail, another engine's GEMMs) still overlap.  Another PROCESS on the same card cannot be chained;
+// for that case a give-up is sticky: after the first one the device stays on the per-step kernels for the rest of the process
+// (am_lstm_persist_reenable lifts it), instead of stalling 2 s again on every upload.
+struct PersistGate {
+    std::mutex mu;
+    hipEvent_t last = nullptr;        // completion of the most recent persistent launch on this device ...
+    const am_engine* owner = nullptr; // ... and the engine whose event that is
+    std::atomic<bool> off{false};     // a launch gave up on this device: no persistent form until re-enabled
+};
+constexpr int AM_MAX_DEVICES = 64;
+static PersistGate g_gate[AM_MAX_DEVICES];
+static PersistGate& gate_of(const am_engine* e) { return g_gate[e->device >= 0 && e->device < AM_MAX_DEVICES ? e->device : 0]; }
 
 // Rows per feed-forward chunk of the device-resident path (bounds the activation workspace); tunable for experiments.
 static int64_t env_int(const char* name, int64_t dflt)
@@ -298,6 +319,7 @@ extern "C" int am_engine_create(int device, am_engine** out)
     int n = am_device_count();
     if (n <= 0) return fail(AM_ENODEV, "no HIP device visible (this library has no CPU fallback)");
     if (device < 0 || device >= n) return fail(AM_ENODEV, "device %d out of range (0..%d)", device, n - 1);
+    if (device >= AM_MAX_DEVICES) return fail(AM_ENODEV, "device %d: at most %d devices are supported", device, AM_MAX_DEVICES);
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -305,11 +327,13 @@ extern "C" int am_engine_create(int device, am_engine** out)
         return fail(AM_ENODEV, "device %d is %s; libamfwd is built for gfx950 (MI355X) only", device, prop.gcnArchName);
     am_engine* e = new am_engine();
     e->device = device;
-    snprintf(e->name, sizeof(e->name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    e->n_cus = prop.multiProcessorCount;
+    snprintf(e->name, sizeof(e->name), "%s (%s, %d CUs)", prop.name[0] ? prop.name : "AMD GPU", prop.gcnArchName, prop.multiProcessorCount);
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&e->chain[0], hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&e->chain[1], hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&e->s2_tail, hipEventDisableTiming) != hipSuccess) { delete e; return fail(AM_EHIP, "hipStreamCreate failed"); }
+        hipEventCreateWithFlags(&e->s2_tail, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->persist_done, hipEventDisableTiming) != hipSuccess) { delete e; return fail(AM_EHIP, "hipStreamCreate failed"); }
     hipError_t r = init_kernels();
     if (r != hipSuccess) { (void)hipStreamDestroy(e->stream); delete e; return fail(AM_EHIP, "kernel init failed: %s", hipGetErrorString(r)); }
     *out = e;
@@ -338,6 +362,12 @@ static void engine_teardown(am_engine* e)
     (void)hipStreamSynchronize(e->stream);
     (void)hipStreamSynchronize(e->stream2);
     (void)hipEventDestroy(e->s2_tail);
+    {   // the stream is idle: nobody needs to wait for this engine's last persistent launch any more
+        PersistGate& G = gate_of(e);
+        std::lock_guard<std::mutex> lk(G.mu);
+        if (G.owner == e) { G.last = nullptr; G.owner = nullptr; }
+    }
+    if (e->persist_done) (void)hipEventDestroy(e->persist_done);
     (void)hipStreamDestroy(e->stream2);
     for (auto c : e->chain) if (c) { (void)hipStreamSynchronize(c); (void)hipStreamDestroy(c); }
     for (auto& r : e->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -732,7 +762,7 @@ extern "C" int am_pipeline_destroy(am_pipeline* p)
     for (auto ev : p->ev_chain) if (ev) (void)hipEventDestroy(ev);
     p->drop_graph();
     for (DevBuf* d : {&p->d_shifts, &p->d_add, &p->d_scale, &p->d_rplw, &p->d_rplb, &p->d_rpllb, &p->d_prior, &p->d_x, &p->d_ivec, &p->d_in, &p->d_in_s,
-                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_stack, &p->d_ffsync, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c, &p->d_nact, &p->d_stepoff, &p->d_sync, &p->d_stamps})
+                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_stack, &p->d_ffsync, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c, &p->d_cplane, &p->d_nact, &p->d_stepoff, &p->d_sync, &p->d_stamps})
         d->release();
     for (auto& pl : p->persist) pl.release();
     am_engine* e = p->e;
@@ -1031,9 +1061,14 @@ extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, i
     int planes = 0;
     for (auto* m : p->members) if (ff_stack_shape_ok(m)) planes = std::max(planes, m->n_layers);
     if (planes > 0 && ff_stack_mode() > 0) {
-        AM_TRY(p->d_stack.ensure(sizeof(float) * (size_t)planes * rows * width));
-        AM_TRY(p->d_ffsync.ensure(sizeof(unsigned) * (FF_SYNC_DONE + (size_t)planes * (rows / GEMM_BM))));
-        p->stack_rows = rows; p->stack_width = width; p->stack_planes = planes;
+        if (p->d_stack.ensure(sizeof(float) * (size_t)planes * rows * width) == AM_OK &&
+            p->d_ffsync.ensure(sizeof(unsigned) * (FF_SYNC_DONE + (size_t)planes * (rows / GEMM_BM))) == AM_OK) {
+            p->stack_rows = rows; p->stack_width = width; p->stack_planes = planes;
+        } else {   // (3 to 13 GB per pipeline at the bench sizes) no room for the planes: the per-layer launches need none
+            (void)hipGetLastError();
+            p->d_stack.release();
+            p->stack_planes = 0;
+        }
     } else p->stack_planes = 0;
     }
     const int acc_w = std::max<int>(m0->C_pad, (int)round_up(m0->C, 256));
@@ -1081,7 +1116,7 @@ static int ff_member_forward_stack(am_pipeline* p, int mi, int64_t rows_pad, flo
     }   // test hook: arrival targets nobody reaches -> the waits must time out
     HIP_TRY(hipMemsetAsync(sync + FF_SYNC_QUEUES, 0, sizeof(unsigned) * (FF_SYNC_DONE - FF_SYNC_QUEUES + (size_t)m->n_layers * tiles_m), e->stream));
     const int out_pad = m->L[m->n_layers].out_pad;
-    AM_TRY(run_kernel(e, K_GEMM_STACK, [&] { return launch_gemm_stack(e->stream, a, out_pad); }));
+    AM_TRY(run_kernel(e, K_GEMM_STACK, [&] { return launch_gemm_stack(e->stream, a, out_pad, e->n_cus); }));
     p->used_stack = true;
     return AM_OK;
 }
@@ -1454,7 +1489,8 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
     p->persist.clear();
     p->persist.resize(p->members.size());
     const int pmode = lstm_persist_mode();
-    if (pmode && T > 0 && (size_t)rows_alloc * gw * sizeof(float) < ((size_t)1 << 31)) {
+    bool any_persist = false;
+    if (pmode && !gate_of(e).off.load() && T > 0 && (size_t)rows_alloc * gw * sizeof(float) < ((size_t)1 << 31)) {
         std::vector<int> nact(p->n_active.begin(), p->n_active.end()), soff(p->step_off.begin(), p->step_off.end());
         AM_TRY(p->d_nact.ensure(sizeof(int) * nact.size()));
         AM_TRY(p->d_stepoff.ensure(sizeof(int) * soff.size()));
@@ -1470,12 +1506,14 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
             if (!fits) continue;
             auto& pl = p->persist[mi];
             const int U_pad = m->L[0].U_pad;
-            const int cap = lstm_persist_capacity(U_pad, m->n_layers);
+            const int max_wgs = lstm_persist_resident_wgs(U_pad, e->n_cus);
+            const int cap = lstm_persist_capacity(U_pad, m->n_layers, max_wgs);
             if (cap <= 0) continue;
             bool ok = true;
             for (int base = 0; base < n_utts && ok; base += cap) {
                 LstmPersistArgs pa{};
                 pa.n_layers = m->n_layers; pa.U_pad = U_pad; pa.T = (int)T; pa.slot_base = base; pa.slot_cap = std::min(cap, n_utts - base);
+                pa.max_wgs = max_wgs;
                 if (!plan_lstm_persist(pa, pa.slot_cap, nact.data(), nullptr)) { ok = false; break; }
                 staging.emplace_back(lstm_persist_cum_size(pa));
                 plan_lstm_persist(pa, pa.slot_cap, nact.data(), staging.back().data());
@@ -1486,10 +1524,11 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
                 HIP_TRY(hipMemcpyAsync(pl.cums.back().p, staging.back().data(), sizeof(unsigned) * staging.back().size(), hipMemcpyHostToDevice, e->stream));
                 pl.chunks.push_back(pa);
             }
-            if (ok) pl.form = 1; else pl.release();
+            if (ok) { pl.form = 1; any_persist = true; } else pl.release();
         }
         AM_TRY(sync_all(e));   // the staging vectors go out of scope here
     }
+    if (any_persist) AM_TRY(p->d_cplane.ensure(sizeof(float) * rows_alloc * upad * max_layers));   // written before it is read: no memset
     AM_TRY(sync_all(e));
     p->drop_graph();
     p->n = N; p->n_packed = NP; p->n_slots = n_utts; p->has_ivec = ivec != nullptr; p->timedelay = timedelay;
@@ -1499,6 +1538,28 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
 
 static int lstm_enqueue(am_pipeline* p);
 extern "C" int am_lstm_fallback_count(void) { return g_lstm_fallbacks.load(); }
+
+extern "C" int am_lstm_persist_enabled(int device)
+{
+    if (device < 0 || device >= AM_MAX_DEVICES) return 0;
+    return (lstm_persist_mode() != 0 && !g_gate[device].off.load()) ? 1 : 0;
+}
+
+extern "C" int am_lstm_persist_reenable(int device)
+{
+    if (device < 0 || device >= AM_MAX_DEVICES) return fail(AM_EINVAL, "am_lstm_persist_reenable: bad device %d", device);
+    g_gate[device].off.store(false);
+    return AM_OK;
+}
+
+extern "C" int am_pipeline_recurrent_form(am_pipeline* p, int* n_persistent, int* n_members)
+{
+    if (!p || !n_persistent || !n_members || p->mode != 2) return fail(AM_EINVAL, "am_pipeline_recurrent_form: nothing uploaded (am_lstm_upload)");
+    *n_members = (int)p->members.size();
+    *n_persistent = 0;
+    for (auto& pl : p->persist) *n_persistent += pl.form == 1;
+    return AM_OK;
+}
 
 // After a synchronisation: did the persistent recurrent kernel give up on a wait (lstm_persist_kernel's abort flag)?
 static int persist_check(am_pipeline* p)
@@ -1510,8 +1571,10 @@ static int persist_check(am_pipeline* p)
         // A wait ran into its 2 s bound (the kernel's workgroups were not all resident -- e.g. another process holds CUs -- or a
         // hand-off was lost).  Every workgroup has left; the pass is invalid.  Repeat it once on the per-step kernels (same
         // bits), keep this upload on them, and say so: never a wrong result, never a hung GPU.
-        fprintf(stderr, "libamfwd: the persistent recurrent kernel gave up on an inter-workgroup wait; repeating the pass on the per-step kernels\n");
+        fprintf(stderr, "libamfwd: the persistent recurrent kernel gave up on an inter-workgroup wait; repeating the pass on the per-step kernels\n"
+                        "libamfwd: device %d stays on the per-step recurrent kernels for the rest of this process (am_lstm_persist_reenable lifts that)\n", p->e->device);
         ++g_lstm_fallbacks;
+        gate_of(p->e).off.store(true);
         for (auto& pl : p->persist) pl.release();
         p->drop_graph();
         p->results_valid = true;
@@ -1532,9 +1595,10 @@ extern "C" int am_lstm_run(am_pipeline* p)
     auto eager = [&] { const int rc = lstm_enqueue(p); if (rc != AM_OK) p->results_valid = false; return rc; };
     // with the persistent form a pass is a handful of launches on two streams: nothing to gain from a graph, and a replayed
     // graph serialises the second stream's branch (measured: 10.2 ms replayed against 8.8 ms eager)
-    bool all_persistent = !p->persist.empty();
-    for (size_t mi = 0; mi < p->members.size() && all_persistent; ++mi) all_persistent = mi < p->persist.size() && p->persist[mi].form == 1;
-    if (e->profile || all_persistent || !lstm_use_graph()) return eager();   // per-kernel events need eager launches
+    // (and a pass with a persistent launch in it waits for another engine's event, which a stream capture does not admit)
+    bool any_persistent = false;
+    for (auto& pl : p->persist) any_persistent = any_persistent || pl.form == 1;
+    if (e->profile || any_persistent || !lstm_use_graph()) return eager();   // per-kernel events need eager launches
     if (p->graph_exec) { HIP_TRY(hipGraphLaunch(p->graph_exec, e->stream)); return AM_OK; }
     if (p->lstm_runs++ == 0) return eager();          // one-shot use: eager (no capture / instantiate cost)
     // second run on the same upload: capture the launch sequence once, then replay it
@@ -1670,6 +1734,7 @@ static int lstm_enqueue(am_pipeline* p)
         float* Hall = p->d_H.as<float>();
         float* Call = p->d_c.as<float>();
         if (p->persist[mi].form == 1) {
+            float* Cplanes = p->d_cplane.as<float>();
             // the whole stack and time axis in one persistent launch per chunk of utterance slots (lstm_persist_kernel)
             static const bool want_stamps = env_int("AM_LSTM_STAMPS", 0) != 0;
             static const bool overlap_ok = env_int("AM_LSTM_OVERLAP", 1) != 0;
@@ -1682,7 +1747,7 @@ static int lstm_enqueue(am_pipeline* p)
                     s.G = l == 0 ? p->d_G.as<float>() : nullptr;
                     s.bias = Ly.b.as<float>(); s.Wup = l == 0 ? nullptr : Ly.W.as<float>(); s.Wlat = Ly.Wlat.as<float>();
                     s.Hin = l == 0 ? nullptr : Hall + (l - 1) * h_stride;
-                    s.H = Hall + l * h_stride; s.Cst = Call + l * c_stride;
+                    s.H = Hall + l * h_stride; s.Cst = Cplanes + l * h_stride;
                 }
                 pa.n_active = p->d_nact.as<int>(); pa.step_off = p->d_stepoff.as<int>(); pa.cum = p->persist[mi].cums[ci].as<unsigned>();
                 pa.counters = p->d_sync.as<unsigned>(); pa.abort_flag = p->d_sync.as<int>() + 63;
@@ -1709,7 +1774,14 @@ static int lstm_enqueue(am_pipeline* p)
                     HIP_TRY(hipEventRecord(p->ev_fork, e->stream));            // the counters are zero from here on
                     HIP_TRY(hipStreamWaitEvent(e->stream2, p->ev_fork, 0));
                 }
-                AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_persist(e->stream, pa); }));
+                {   // one persistent launch at a time per device (PersistGate): wait for the previous one, whoever launched it
+                    PersistGate& G = gate_of(e);
+                    std::lock_guard<std::mutex> lk(G.mu);
+                    if (G.last && G.owner != e) HIP_TRY(hipStreamWaitEvent(e->stream, G.last, 0));
+                    AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_persist(e->stream, pa); }));
+                    HIP_TRY(hipEventRecord(e->persist_done, e->stream));
+                    G.last = e->persist_done; G.owner = e;
+                }
                 if (split_rows > 0) AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_gate(e->stream2, pa, NL - 1, (int)split_step - 1); }, e->stream2));
             }
             p->used_persist = true;
@@ -1747,6 +1819,7 @@ static int lstm_enqueue(am_pipeline* p)
             GemmArgs ga = g;
             ga.M_pad = (int)split_rows;
             ga.queue = p->d_sync.as<int>() + 62;   // zeroed with the arrival counters, before the fork
+            ga.n_cus = e->n_cus;
             AM_TRY(run_kernel(e, K_GEMM_OUT, [&] { return launch_gemm(e->stream2, ga); }, e->stream2));
             AM_TRY(final_finish(p, split_rows, p->d_out.as<float>(), p->d_dst.as<int>(), 0, e->stream2));
             HIP_TRY(hipEventRecord(p->ev_join, e->stream2));

@@ -42,6 +42,7 @@ struct GemmArgs {
     int epi; float alpha;
     int row_p = 0, row_skip = 0;  // TDNN: output row R reads A row R + (R / row_p) * row_skip (0 = plain GEMM)
     int* queue = nullptr;         // work-queue mode: device counter (zero before the launch) the blocks pull tile numbers from
+    int n_cus = 256;              // work-queue mode: CUs of the device (grid = one block per CU)
 };
 hipError_t init_kernels();  // once per device after hipSetDevice
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
@@ -66,7 +67,7 @@ struct GemmStackArgs {
     int test_extra;              // added to every wait's target (0; the give-up test sets 1)
     unsigned long long* stamps;  // diagnostic [workgroups][16] or nullptr (am_ff_stack_stamps): selects the STAMPS instantiation
 };
-hipError_t launch_gemm_stack(hipStream_t s, const GemmStackArgs& a, int out_n_pad);
+hipError_t launch_gemm_stack(hipStream_t s, const GemmStackArgs& a, int out_n_pad, int n_cus);
 
 // split-f16 precision mode (see gemm_nt_split_kernel): operands are hi/lo half matrices
 struct SplitGemmArgs {
@@ -150,7 +151,7 @@ struct LstmPersistLayer {
     const float* Wlat;   // [4*U_pad, U_pad] gate-tiled rows
     const float* Hin;    // layers >= 1: packed H plane of the layer below [>= NP, U_pad]
     float* H;            // this layer's packed H plane
-    float* Cst;          // this layer's cell state [slots, U_pad]
+    float* Cst;          // this layer's cell-state plane, time-major packed like H [>= NP, U_pad] (written once per address and launch)
     int n_groups;        // row groups of this layer
     int group0;          // index of its first group among all groups (counter index)
 };
@@ -158,6 +159,7 @@ struct LstmPersistArgs {
     LstmPersistLayer L[LSTM_MAX_LAYERS];
     int n_layers, U_pad, T;
     int n_groups_total;            // grid = n_groups_total * (U_pad / 16)
+    int max_wgs;                   // workgroups of this kernel the device holds at once (lstm_persist_resident_wgs): the plan's budget
     int slot_base, slot_cap;       // this launch covers the utterance slots [slot_base, slot_base + slot_cap) (longest first: a chunk of a larger file)
     const int* n_active;           // device [T]
     const int* step_off;           // device [T + 1]
@@ -170,7 +172,8 @@ struct LstmPersistArgs {
 // stack does not fit the persistent form (then the per-step kernels run).  cum_out: [n_groups_total][T] arrival targets.
 bool plan_lstm_persist(LstmPersistArgs& a, int n_slots, const int* n_active_host, unsigned* cum_out /*nullable*/);
 size_t lstm_persist_cum_size(const LstmPersistArgs& a);   // entries of `cum`
-int lstm_persist_capacity(int U_pad, int n_layers);       // utterance slots one launch can take (0: this shape has no persistent form)
+int lstm_persist_resident_wgs(int U_pad, int n_cus);      // co-resident workgroups of the kernel on a device of n_cus CUs (0: none)
+int lstm_persist_capacity(int U_pad, int n_layers, int max_wgs);   // utterance slots one launch can take (0: this shape has no persistent form)
 hipError_t launch_lstm_persist(hipStream_t s, const LstmPersistArgs& a);
 hipError_t launch_lstm_gate(hipStream_t s, const LstmPersistArgs& a, int layer, int tcol);   // returns once `layer` has finished step tcol
 

@@ -299,19 +299,19 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g)
     const int tiles_m = g.M_pad / GEMM_BM;
     if (g.N_pad % 256 == 0) {
         const int tiles_n = g.N_pad / 256, n_tiles = tiles_m * tiles_n;
-        const int grid = g.queue ? std::min(n_tiles, 256) : n_tiles;     // work-queue mode: one block per CU slot is enough
+        const int grid = g.queue ? std::min(n_tiles, g.n_cus) : n_tiles;     // work-queue mode: one block per CU slot is enough
         hipLaunchKernelGGL((gemm_nt_f32_kernel<256, 32>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_256, s,
                            g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 32, g.act, g.epi, g.alpha, g.row_p, g.row_skip, g.queue, n_tiles);
     } else if (g.N_pad % 192 == 0 && !getenv("AM_GEMM_384")) {
         // 1909 classes -> 1920 = 10 x 192: half the tile of the 384-wide form (the round-1 choice, kept behind AM_GEMM_384 for A/B runs) --
         // 96 accumulator registers instead of 192, no spills, and twice as many tiles to fill the last round of a launch with
         const int tiles_n = g.N_pad / 192, n_tiles = tiles_m * tiles_n;
-        const int grid = g.queue ? std::min(n_tiles, 256) : n_tiles;
+        const int grid = g.queue ? std::min(n_tiles, g.n_cus) : n_tiles;
         hipLaunchKernelGGL((gemm_nt_f32_kernel<192, 32>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_192, s,
                            g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 32, g.act, g.epi, g.alpha, g.row_p, g.row_skip, g.queue, n_tiles);
     } else if (g.N_pad % 384 == 0) {
         const int tiles_n = g.N_pad / 384, n_tiles = tiles_m * tiles_n;
-        const int grid = g.queue ? std::min(n_tiles, 512) : n_tiles;
+        const int grid = g.queue ? std::min(n_tiles, 2 * g.n_cus) : n_tiles;
         hipLaunchKernelGGL((gemm_nt_f32_kernel<384, 16>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_384, s,
                            g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 16, g.act, g.epi, g.alpha, g.row_p, g.row_skip, g.queue, n_tiles);
     } else return hipErrorInvalidValue;
@@ -534,10 +534,10 @@ hipError_t init_stack_kernel()
     return e;
 }
 
-hipError_t launch_gemm_stack(hipStream_t s, const GemmStackArgs& a, int out_n_pad)
+hipError_t launch_gemm_stack(hipStream_t s, const GemmStackArgs& a, int out_n_pad, int n_cus)
 {
-    if (a.n_hidden < 1 || a.n_hidden > GEMM_STACK_MAX_HIDDEN || a.tiles_m <= 0 || a.cum_total <= 0) return hipErrorInvalidValue;
-    const int grid = (int)std::min<long long>((long long)a.tiles_m * a.cum_total, 256);   // one workgroup per CU
+    if (a.n_hidden < 1 || a.n_hidden > GEMM_STACK_MAX_HIDDEN || a.tiles_m <= 0 || a.cum_total <= 0 || n_cus <= 0) return hipErrorInvalidValue;
+    const int grid = (int)std::min<long long>((long long)a.tiles_m * a.cum_total, n_cus);   // one workgroup per CU (speed only: the queue needs no co-residency)
     const bool w192 = out_n_pad % 256 != 0;
     if (w192 && out_n_pad % 192 != 0) return hipErrorInvalidValue;
 #define AM_STACK_LAUNCH(W, S, C) hipLaunchKernelGGL((gemm_stack_kernel<W, S, C>), dim3(grid), dim3(GEMM_THREADS), GEMM_STACK_LDS, s, a)
@@ -1503,8 +1503,11 @@ __global__ __launch_bounds__(512) void lstm_thin_kernel(const LstmWavefrontArgs 
 // so the upward half of step t runs in the shadow of the other workgroups' step t-1, lower layers run ahead freely (every
 // layer has its own time-major H plane, nothing is overwritten), and a step's cost approaches its MFMA time.
 // Row groups are re-cut EVERY step: with `tiles` 16-row tiles active, group g of NG takes tiles [g q, g q + q), q =
-// ceil(tiles / NG) -- all workgroups of a layer stay busy while utterances end (the cell state therefore travels through
-// memory like h).  Rows past n_active[t] are never loaded: in the packed layout they alias rows of step t+1 that another
+// ceil(tiles / NG) -- all workgroups of a layer stay busy while utterances end.  The cell state therefore travels through
+// memory like h, and like h through a TIME-MAJOR plane of its own (row step_off[t] + slot): an address is written once per
+// launch, so no XCD's L2 can hold an older version of a line a slot's next owner reads (a per-slot array rewritten in place
+// would rely on sc1 stores dropping the writer's line and on where the workgroups land; round 3).
+// Rows past n_active[t] are never loaded: in the packed layout they alias rows of step t+1 that another
 // XCD may not have written yet, and a line fetched early would stay stale in this XCD's L2.
 // Same summation order as the per-step kernels: per K half, 64-k chains from zero folded in k order (upward batches, then
 // lateral), (half 0 + half 1) + G/bias -- a frame's posteriors do not depend on the form that computed them.
@@ -1690,6 +1693,7 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
     const int rows_valid = n_act - row0;                       // > 0
     const int slot0 = a.slot_base + row0;                       // first utterance slot of this group's rows
     const unsigned r_t = (unsigned)(a.step_off[t] + slot0);     // its packed row at step t
+    const unsigned r_p = t > 0 ? (unsigned)(a.step_off[t - 1] + slot0) : 0u;   // ... and at step t - 1 (h and c of the previous step)
     persist_stamp(a, gidx, ut, t, 0);
     if (NBU) {   // upward product: needs step t of the layer below (which runs ahead: normally no wait at all)
         if (!persist_wait(a, a.L[li - 1].group0, a.L[li - 1].n_groups, t, s_flag)) return false;
@@ -1713,7 +1717,7 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
     };
     auto fetch_epilogue = [&] {
         if (!NBU) fetch_g();
-        if (live && t > 0) cq = ld_sc1_b128(crs, ((unsigned)(slot0 + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u);
+        if (live && t > 0) cq = ld_sc1_b128(crs, ((r_p + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u);
     };
     auto lat_wait = [&] { return persist_wait(a, Ly.group0, Ly.n_groups, t - 1, s_flag); };   // step t-1 of every group of this layer
     f32x4 acc[NT];
@@ -1729,7 +1733,7 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
         persist_stamp(a, gidx, ut, t, 2);
     }
     f32x4 wnone[1][LSTM_KS] = {};   // stands in for the absent upward weights of a lateral-only pipeline (never read)
-    if (t > 0) ok = persist_products<0, NBL, true, NT>(Ly.H, 0u, Ly.H, (unsigned)(a.step_off[t - 1] + slot0), rows_valid, U_pad, wnone, wl, acc, smem, tid, l15, lq, kh, lat_wait, fetch_epilogue) && ok;
+    if (t > 0) ok = persist_products<0, NBL, true, NT>(Ly.H, 0u, Ly.H, r_p, rows_valid, U_pad, wnone, wl, acc, smem, tid, l15, lq, kh, lat_wait, fetch_epilogue) && ok;
     else if (!NBU) fetch_epilogue();
     if (!ok) return false;
     persist_stamp(a, gidx, ut, t, 4);
@@ -1759,7 +1763,7 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
             cn[u] = c;
             hn[u] = go * am_tanh_rec(c);
         }
-        st_sc1_b128(crs, ((unsigned)(slot0 + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u, cn);
+        st_sc1_b128(crs, ((r_t + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u, cn);
         st_sc1_b128(hrs, ((r_t + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u, hn);
     }
     persist_stamp(a, gidx, ut, t, 5);
@@ -1862,11 +1866,23 @@ static bool lstm_persist_scratch_free(int U_pad)
     return st == 1;
 }
 
-int lstm_persist_capacity(int U_pad, int n_layers)
+// Workgroups of lstm_persist_kernel the device holds at once: the occupancy the runtime reports for this kernel with its
+// dynamic LDS (147 KB: one per CU) x the CUs the device really has (a partitioned or harvested part has fewer than 256).
+int lstm_persist_resident_wgs(int U_pad, int n_cus)
+{
+    if (U_pad != 256 && U_pad != 512) return 0;
+    int per_cu = 0;
+    const hipError_t e = U_pad == 512 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)lstm_persist_kernel<4>, 512, LSTM_PERSIST_LDS)
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)lstm_persist_kernel<2>, 512, LSTM_PERSIST_LDS);
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return per_cu > 0 ? n_cus : 0;   // the groups are laid out one workgroup per CU even where two would fit
+}
+
+int lstm_persist_capacity(int U_pad, int n_layers, int max_wgs)
 {
     if ((U_pad != 256 && U_pad != 512) || n_layers < 1 || n_layers > LSTM_MAX_LAYERS) return 0;
     if (!lstm_persist_scratch_free(U_pad)) return 0;
-    const int nb = U_pad / LSTM_KB, budget = 256 / (U_pad / 16);
+    const int nb = U_pad / LSTM_KB, budget = max_wgs / (U_pad / 16);
     int tiles = 0;
     for (int t0 = 1; t0 <= 4096; ++t0) {
         int total = 0;
@@ -1881,7 +1897,7 @@ bool plan_lstm_persist(LstmPersistArgs& a, int n_slots, const int* n_active, uns
 {
     if (a.n_layers < 1 || a.n_layers > LSTM_MAX_LAYERS || a.T <= 0 || n_slots <= 0) return false;
     if (a.U_pad != 256 && a.U_pad != 512) return false;
-    const int nb = a.U_pad / LSTM_KB, tpg = a.U_pad / 16, budget = 256 / tpg;   // groups the chip can hold at one workgroup per CU
+    const int nb = a.U_pad / LSTM_KB, tpg = a.U_pad / 16, budget = a.max_wgs / tpg;   // groups the chip can hold at one workgroup per CU
     const int tiles0 = (n_slots + 15) / 16;
     int ng[LSTM_MAX_LAYERS], total = 0;
     for (int l = 0; l < a.n_layers; ++l) {
@@ -1957,7 +1973,7 @@ hipError_t launch_lstm_gate(hipStream_t s, const LstmPersistArgs& a, int layer, 
 hipError_t launch_lstm_persist(hipStream_t s, const LstmPersistArgs& a)
 {
     const int grid = a.n_groups_total * (a.U_pad / 16);
-    if (grid <= 0 || grid > 256) return hipErrorInvalidValue;
+    if (grid <= 0 || grid > a.max_wgs) return hipErrorInvalidValue;   // every workgroup must be resident: never more than the device holds
     if (a.U_pad == 512) hipLaunchKernelGGL(lstm_persist_kernel<4>, dim3(grid), dim3(512), LSTM_PERSIST_LDS, s, a);
     else if (a.U_pad == 256) hipLaunchKernelGGL(lstm_persist_kernel<2>, dim3(grid), dim3(512), LSTM_PERSIST_LDS, s, a);
     else return hipErrorInvalidValue;

@@ -392,6 +392,12 @@ class Pipeline:
         self.lstm_run()
         return self.lstm_download(out)
 
+    def recurrent_form(self):
+        """(members that run as ONE persistent launch per chunk of utterance slots, members) of the current recurrent upload."""
+        a, b = C.c_int(0), C.c_int(0)
+        check(self._lib.am_pipeline_recurrent_form(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     # stage entry point -------------------------------------------------------------------------------
     def frontend_apply(self, x_ext, ivec=None, n=None, halo_lo=0, halo_hi=0):
         x_ext = _f32(x_ext)

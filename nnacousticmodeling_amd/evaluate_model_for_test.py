@@ -60,7 +60,12 @@ def evaluateModelTestTri(model, data, offsets, PIP, LMW, ap=None, GPUID=0, testO
     same segmentations as the reference binary) when ``kaldiTri1909.img`` exists under ``recogdir``; "subprocess" runs the
     reference's ``PhoneRecog`` executable as the reference does; without the graph image "auto" stops after writing the
     posteriors and returns NaN.  ``write_lab=False`` skips the ``.lab``/``.scp`` files (442 MB for the core test set),
-    which only the external executable needs."""
+    which only the external executable needs.
+
+    With several GPUs every shard owns whole utterances (frame ranges cut at utterance boundaries, or utterance bins for
+    recurrent nets), writes their ``.lab`` files from its own page-locked block and decodes them on its own GPU straight from
+    device memory (``PosteriorRunner.map_shards``): nothing is gathered into one array, and with ``write_lab=False`` the
+    posteriors never leave the devices."""
     testList = open(uttlistdir + "/" + testOrDev + ".list").readlines()
     if len(testList) != len(offsets) - 1:
         print("Error: wrong number of utterances")
@@ -69,29 +74,48 @@ def evaluateModelTestTri(model, data, offsets, PIP, LMW, ap=None, GPUID=0, testO
     if progress:
         print("Calculating network outputs")
     img = str(Path(recogdir, "kaldiTri1909.img"))
-    # without .lab files and with the in-process decoder on one GPU nothing has to leave the device: the decoder reads the
-    # posteriors where the network wrote them (no 442 MB download + upload for the core test set)
-    resident = (not write_lab) and run_decoder in ("auto", "gpu") and len(devices) == 1 and os.path.isfile(img)
-    pipeline = y = None
-    if resident:
-        shifts, ft = ([0], None) if frontend is None else frontend
-        pipeline = get_runner(devices).resident(model, data, offsets, shifts=shifts, ft=ft, ivectors=ivectors, prior=ap, recurrent=rnn)
-    else:
-        y = compute_posteriors(model, data, offsets, ap=ap, devices=devices, rnn=rnn, frontend=frontend, ivectors=ivectors)
+    have_img = os.path.isfile(img)
+    in_process = bool(run_decoder) and run_decoder in ("auto", "gpu") and have_img
+    need_lab = write_lab or run_decoder == "subprocess"
     labDirOut = Path(tmpDir)
     labDirOut.mkdir(exist_ok=True, parents=True)
-    offsets = np.asarray(offsets)
+    offsets = np.asarray(offsets, dtype=np.int64)
+    names = [f.strip() for f in testList]
+    shifts, ft = ([0], None) if frontend is None else frontend
+    if rnn and len(list(shifts)) != 1:
+        raise ValueError("operands could not be broadcast together: recurrent networks take un-spliced frames")
+
+    def make_decoder(engine):
+        from .phone_recog import PhoneRecog
+        return PhoneRecog(engine, img, -abs(PIP), LMW)
+
+    def per_shard(ctx):
+        """This shard's utterances: .lab files from its own host block, segmentations from its own GPU."""
+        segs = None
+        if in_process:   # first: the decode launches run on the device while the host part below writes files
+            segs = ctx.decoder(("viterbi", img, float(PIP), float(LMW)), make_decoder).recognise_pipeline(ctx.pipeline, ctx.local_offsets)
+        if need_lab:
+            y = ctx.download()
+            for j, u in enumerate(ctx.utts):
+                saveBin(str(Path(labDirOut, names[u] + ".lab")), y[ctx.local_offsets[j]:ctx.local_offsets[j + 1], :])
+        return ctx.utts, segs
+
+    runner = get_runner(devices)
+    shard_results = runner.map_shards(as_ensemble(model), data, per_shard, offsets=offsets, shifts=shifts, ft=ft, ivectors=ivectors,
+                                      prior=ap, recurrent=rnn, timedelay=0)
     scp = Path(labDirOut, testOrDev + ".scp")
-    if y is not None and (write_lab or run_decoder == "subprocess"):
+    if need_lab:
         if progress:
             print("Writing output files")
-        scp = write_posteriors(y, offsets, testList, labDirOut, testOrDev)
+        with open(str(scp), "wt") as fscp:   # list order, as the reference writes it (evaluateModelForTest.py:43-45,91-93,114-116)
+            for f in names:
+                fscp.write(str(Path(labDirOut, f + ".lab")) + "\n")
 
     recog = recogdir + "/PhoneRecog" + (".exe" if os.name == "nt" else "")
     result_txt = str(Path(labDirOut, "vysledek_" + testOrDev + ".txt"))
     if not run_decoder:
         return float("nan")
-    if not os.path.isfile(img):
+    if not have_img:
         if run_decoder == "auto":
             print("kaldiTri1909.img not found under %s: posteriors written to %s, decoding skipped" % (recogdir, scp))
             return float("nan")
@@ -101,13 +125,12 @@ def evaluateModelTestTri(model, data, offsets, PIP, LMW, ap=None, GPUID=0, testO
         cmd = [recog, str(scp), img, result_txt, str(-abs(PIP)), str(LMW)]
         subprocess.run(cmd, cwd=os.getcwd())
     else:
-        from .phone_recog import PhoneRecog, base_name_copy, write_mlf
-        runner = get_runner(devices)
-        dec = PhoneRecog(runner._dev(devices[0]).engine, img, -abs(PIP), LMW)
-        results = dec.recognise_pipeline(pipeline, offsets) if pipeline is not None else dec.recognise(y, offsets)
-        names = [base_name_copy(str(Path(labDirOut, f.strip() + ".lab"))) for f in testList]
-        write_mlf(result_txt, names, results)
-        dec.close()
+        from .phone_recog import base_name_copy, write_mlf
+        results = [None] * len(names)
+        for utts, segs in shard_results:
+            for u, sg in zip(utts, segs):
+                results[int(u)] = sg
+        write_mlf(result_txt, [base_name_copy(str(Path(labDirOut, f + ".lab"))) for f in names], results)
     p39 = str(Path(labDirOut, "vysledek_" + testOrDev + "_p39.txt"))
     convert_results(str(Path(recogdir, "phones.60-48-39.map")), result_txt, p39)
     ref = loadMlf(str(Path(recogdir, testOrDev + "_ref.mlf")))

@@ -40,6 +40,40 @@ def predict(model, x, offsets, num_classes, network, gpu, winlen, timedelay, ft,
     return runner.forward_ff(model, x, shifts=range(-winhalf, winhalf + 1), ft=ft, combine=combine)
 
 
+def predict_to_npy(path, model, x, offsets, num_classes, network, gpu, winlen, timedelay, ft, progress=True, combine=AM_COMBINE_LOGITS):
+    """``np.save(path, predict(...))`` without the gathered array: the ``.npy`` is created as a memory map (same bytes as
+    ``np.save`` writes: predict_folds.py:220,240) and every GPU's shard thread copies its own rows into it from its own
+    page-locked block, in parallel (``PosteriorRunner.map_shards``).  Returns the path written (``.npy`` appended like np.save)."""
+    devices = list(gpu) if isinstance(gpu, (list, tuple)) else [gpu]
+    runner = get_runner(devices)
+    if model.num_classes != num_classes:
+        raise ValueError("model has %d classes, expected %d" % (model.num_classes, num_classes))
+    path = str(path)
+    if not path.endswith(".npy"):
+        path += ".npy"
+    x = np.asarray(x)
+    out = np.lib.format.open_memmap(path, mode="w+", dtype=np.float32, shape=(x.shape[0], num_classes))
+    recurrent = is_nn_recurrent(network)
+    if recurrent:
+        offsets = np.asarray(offsets, dtype=np.int64)
+
+    def per_shard(ctx):
+        y = ctx.download()
+        if ctx.lo is not None:                       # feed-forward: one contiguous range of the file
+            out[ctx.lo:ctx.hi] = y
+        else:                                        # recurrent: this shard's utterances, wherever they lie in the file
+            for j, u in enumerate(ctx.utts):
+                out[offsets[u]:offsets[u + 1]] = y[ctx.local_offsets[j]:ctx.local_offsets[j + 1]]
+
+    winhalf = int(winlen / 2)
+    shifts = [0] if recurrent else range(-winhalf, winhalf + 1)
+    runner.map_shards(model, x, per_shard, offsets=offsets if recurrent else None, shifts=shifts, ft=ft, recurrent=recurrent,
+                      timedelay=timedelay, combine=combine)
+    out.flush()
+    del out
+    return path
+
+
 def build_parser():
     parser = argparse.ArgumentParser(description="MI355X fold prediction (drop-in for predict_folds.py)")
     parser.add_argument("--network", "-n", default="ff", help='Neural network type, "ff" or "lstm"')
@@ -139,9 +173,8 @@ def main(arg_list=None):
             sys.exit(2)
         # mean of the per-fold log-posteriors, renormalised (predict_folds.py:199-220), all members resident on the GPU
         from .networks import NNWithRPL
-        y_out = predict(NNWithRPL(None, models), x, offsets, num_classes, args.network, devices, winlen, args.timedelay, ft,
-                        not args.no_progress, combine=AM_COMBINE_LOGPOST)
-        np.save(str(Path(args.fold_output_dir, args.fold_output_dev)), y_out)
+        predict_to_npy(Path(args.fold_output_dir, args.fold_output_dev), NNWithRPL(None, models), x, offsets, num_classes, args.network,
+                       devices, winlen, args.timedelay, ft, not args.no_progress, combine=AM_COMBINE_LOGPOST)
     else:
         n_folds = 0
         for fold, model in fold_models():
@@ -150,8 +183,8 @@ def main(arg_list=None):
             offsets = np.load(str(Path(args.fold_data_dir, args.fold_offset_pattern.format(fold)))) if recurrent else None
             if args.ivector_dir:
                 x = concat_ivectors(x, np.load(str(Path(args.fold_data_dir, args.fold_ivector_pattern.format(fold)))))
-            y = predict(model, x, offsets, num_classes, args.network, devices, winlen, args.timedelay, ft, not args.no_progress)
-            np.save(str(Path(args.fold_output_dir, args.fold_output_pattern.format(fold))), y)
+            predict_to_npy(Path(args.fold_output_dir, args.fold_output_pattern.format(fold)), model, x, offsets, num_classes, args.network,
+                           devices, winlen, args.timedelay, ft, not args.no_progress)
             n_folds += 1
         if n_folds == 0:
             print("Error: No fold networks found")

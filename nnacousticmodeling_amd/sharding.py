@@ -1,14 +1,22 @@
-"""Shard the posterior computation over the GPUs of one node and gather on the host.
+"""Shard the posterior computation over the GPUs of one node; every shard delivers its own rows.
 
 Frames (feed-forward) and utterances (recurrent) are independent, so the path shards with no collective
 (SURVEY.md 8e): contiguous frame ranges with a +-context read halo for ``ff`` -- the splice clamps only at the global
 ends of the file (reference kw_utils.py:29-33), never at shard or utterance boundaries -- and longest-first bins of
-whole utterances for ``lstm``.  One host thread drives each GPU through its own engine (ctypes releases the GIL);
-the gather is a plain copy into the single output array.
+whole utterances for ``lstm``.  One host thread drives each logical shard through its own engine (ctypes releases the GIL).
+
+Two ways out of a shard:
+* ``forward_ff`` / ``forward_lstm``: the reference's contract, ONE ``[N, C]`` array in file order (host-side gather; every
+  shard downloads straight into its slice of one page-locked block);
+* ``map_shards``: each shard thread hands its rows to a caller-supplied function while they are still on its GPU and/or in
+  its own page-locked block -- the ``.lab`` writer, the in-process decoder and the ``.npy`` writer use this, so N GPUs do not
+  funnel 7.6 KB per frame into one array (and ``evaluate --no-lab`` never downloads the posteriors at all).
 """
 from __future__ import annotations
 
+import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -29,6 +37,26 @@ def ff_shards(n_frames, n_parts, context):
         hi = n_frames * (g + 1) // n_parts
         if hi > lo:
             out.append((lo, hi, min(context, lo), min(context, n_frames - hi)))
+    return out
+
+
+def ff_shards_aligned(offsets, n_parts, context):
+    """Frame ranges cut at UTTERANCE boundaries (each shard owns whole utterances, so it can write their ``.lab`` files and
+    decode them by itself); the read halo still crosses the boundary, as the reference's splice does.
+    -> [(lo, hi, halo_lo, halo_hi, u_lo, u_hi), ...]: frames [lo, hi) = utterances [u_lo, u_hi).  Empty shards are dropped."""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    n_utts, n = len(offsets) - 1, int(offsets[-1])
+    n_parts = max(1, min(int(n_parts), max(n_utts, 1)))
+    cuts = [0]
+    for g in range(1, n_parts):
+        u = int(np.searchsorted(offsets, n * g // n_parts, side="left"))   # first boundary at or after the even cut
+        cuts.append(min(max(u, cuts[-1]), n_utts))
+    cuts.append(n_utts)
+    out = []
+    for u_lo, u_hi in zip(cuts[:-1], cuts[1:]):
+        lo, hi = int(offsets[u_lo]), int(offsets[u_hi])
+        if u_hi > u_lo:
+            out.append((lo, hi, min(context, lo), min(context, n - hi), u_lo, u_hi))
     return out
 
 
@@ -58,6 +86,124 @@ def gather_utterances(x, offsets, utts):
     return np.ascontiguousarray(cat), local
 
 
+def check_offsets(offsets, n):
+    """The utterance table must tile the file: start at 0, never decrease, end at the frame count (the reference checks the
+    last entry, evaluateModelForTest.py:39; rows no utterance covers would otherwise come back uninitialised)."""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    if offsets.ndim != 1 or len(offsets) < 1 or offsets[0] != 0 or offsets[-1] != n or np.any(np.diff(offsets) < 0):
+        raise ValueError("offsets must start at 0, be non-decreasing and end at the number of frames (%d)" % n)
+    return offsets
+
+
+# ---------------------------------------------------------------------------------------------------
+# page-locked result blocks
+# ---------------------------------------------------------------------------------------------------
+def _default_pool_bytes():
+    v = os.environ.get("AM_PINNED_POOL_MB")
+    if v:
+        return int(float(v) * (1 << 20))
+    try:
+        ram = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+    except (ValueError, OSError):
+        ram = 64 << 30
+    return int(min(16 << 30, ram // 4))
+
+
+class PinnedPool:
+    """Page-locked host blocks for posteriors, handed out as explicit LEASES.
+
+    ``take(n, c)`` returns an ``[n, c]`` float32 array on page-locked memory (a view of a block with at least ``n * c``
+    elements) -- a block somebody gave back when one is large enough, else a fresh one.  The array belongs to the caller: it
+    is never handed out again unless the caller returns it with ``give(y)`` (after which ``y`` must not be used).  Blocks are
+    matched by capacity, not by shape, so a corpus of differently sized files re-uses a few blocks.  The pool's page-locked
+    bytes (given-back blocks + outstanding leases) are capped: over the cap the least recently returned blocks are freed
+    first, and a request that still does not fit gets ordinary pageable memory (slower download, never an error)."""
+
+    def __init__(self, alloc, cap_bytes=None):
+        self._alloc = alloc                      # (shape, dtype) -> ndarray on page-locked memory
+        self.cap = _default_pool_bytes() if cap_bytes is None else int(cap_bytes)
+        self._free = []                          # blocks given back, least recently returned first
+        self._leased = {}                        # id(block) -> (weakref to the block, bytes)
+        self._dead = []                          # (id, weakref) of leases whose array was dropped without give(): reaped under the lock
+        self._lock = threading.Lock()
+
+    @staticmethod
+    def _root(y):
+        while isinstance(getattr(y, "base", None), np.ndarray):
+            y = y.base
+        return y
+
+    def _reap(self):
+        """(lock held)  Forget leases whose arrays have been garbage-collected: their blocks are already unpinned.  The weakref
+        callback only queues -- it may run inside any allocation, also while this thread holds the lock."""
+        while self._dead:
+            key, ref = self._dead.pop()
+            ent = self._leased.get(key)
+            if ent is not None and ent[0] is ref:
+                del self._leased[key]
+
+    def _bytes(self):
+        return sum(b.nbytes for b in self._free) + sum(nb for _, nb in self._leased.values())
+
+    def pinned_bytes(self):
+        with self._lock:
+            self._reap()
+            return self._bytes()
+
+    def free_blocks(self):
+        with self._lock:
+            return len(self._free)
+
+    def take(self, n, c):
+        need = int(n) * int(c)
+        if need == 0 or self._alloc is None:
+            return np.empty((n, c), dtype=np.float32)
+        with self._lock:
+            self._reap()
+            best = None
+            for i, b in enumerate(self._free):
+                if b.size >= need and (best is None or b.size < self._free[best].size):
+                    best = i
+            if best is not None:
+                block = self._free.pop(best)
+            else:
+                used = self._bytes()
+                while self._free and used + 4 * need > self.cap:
+                    used -= self._free.pop(0).nbytes            # least recently returned first
+                if used + 4 * need > self.cap:
+                    return np.empty((n, c), dtype=np.float32)   # over the cap: pageable memory
+                block = None
+        if block is None:
+            block = self._alloc((need,), np.float32)            # (outside the lock: page-locking takes ~0.2 ms per MB)
+        key = id(block)
+        ref = weakref.ref(block, lambda r, k=key: self._dead.append((k, r)))
+        with self._lock:
+            self._leased[key] = (ref, block.nbytes)
+        return block[:need].reshape(n, c)
+
+    def give(self, y):
+        """Return a leased array's block to the pool.  Arrays that are not leases of this pool (pageable ones, slices of
+        somebody else's memory) are ignored.  The caller must not touch ``y`` (or views of it) afterwards."""
+        block = self._root(y)
+        with self._lock:
+            self._reap()
+            ent = self._leased.get(id(block))
+            if ent is None or ent[0]() is not block:
+                return False
+            del self._leased[id(block)]
+            self._free.append(block)
+            total = self._bytes()
+            while len(self._free) > 1 and total > self.cap:
+                total -= self._free.pop(0).nbytes
+        return True
+
+    def clear(self):
+        with self._lock:
+            self._free = []
+            self._leased = {}
+            self._dead = []
+
+
 # ---------------------------------------------------------------------------------------------------
 # runner
 # ---------------------------------------------------------------------------------------------------
@@ -68,6 +214,7 @@ class _ShardState:
         self.engine = backend.Engine(device)
         self.models = []          # [(spec, Model)]: holds the spec itself, never a bare id() (ids are reused after GC)
         self.pipeline = backend.Pipeline(self.engine)
+        self.decoders = {}        # key -> decoder bound to this shard's engine (ShardContext.decoder)
 
     def model_for(self, backend, spec):
         for sp, m in self.models:
@@ -89,6 +236,43 @@ class _ShardState:
             else:
                 m.close()
         self.models = kept
+
+
+class ShardContext:
+    """What ``map_shards`` hands to the per-shard function, in the shard's own thread, after its pass has run:
+
+    ``index`` / ``shard``   position in the runner's shard list / the (gpu, replica) pair
+    ``engine``, ``pipeline`` the shard's engine and its pipeline, which holds this shard's posteriors ON THE DEVICE
+    ``utts``                 indices (file order) of the utterances this shard owns, or None (feed-forward without offsets)
+    ``local_offsets``        their offsets inside this shard's rows (``len(utts) + 1`` entries), or None
+    ``lo``, ``hi``           feed-forward: the shard's frame range in the file; recurrent: None
+    ``n``                    rows of this shard
+    ``download()``           -> float32 ``[n, C]`` on the host (page-locked lease of the runner's pool; ``release`` gives it back)
+    ``decoder(key, make)``   a per-engine cache for objects bound to this shard's GPU (the Viterbi decoder)."""
+
+    def __init__(self, runner, index, shard, st, recurrent, utts, local_offsets, lo, hi, n):
+        self._runner, self._st, self._recurrent = runner, st, recurrent
+        self.index, self.shard = index, shard
+        self.engine, self.pipeline = st.engine, st.pipeline
+        self.utts, self.local_offsets, self.lo, self.hi, self.n = utts, local_offsets, lo, hi, n
+        self._host = None
+
+    def download(self):
+        if self._host is None:
+            y = self._runner._out(self.n, self.pipeline.num_classes)
+            self._host = self.pipeline.lstm_download(out=y) if self._recurrent else self.pipeline.ff_download(out=y)
+        return self._host
+
+    def release(self):
+        if self._host is not None:
+            self._runner.pool.give(self._host)
+            self._host = None
+
+    def decoder(self, key, make):
+        d = self._st.decoders.get(key)
+        if d is None:
+            d = self._st.decoders[key] = make(self.engine)
+        return d
 
 
 def _normalise_shards(devices):
@@ -118,9 +302,11 @@ class PosteriorRunner:
 
     ``devices``: list of device ids, or of ``(device, replica)`` pairs for several logical shards per GPU.
     ``backend``: module providing Engine/Model/Pipeline (default: the HIP engine; the CPU-only test-suite injects a
-    stand-in to exercise this host logic without a GPU)."""
+    stand-in to exercise this host logic without a GPU).
+    Result arrays of ``forward_ff`` / ``forward_lstm`` are the caller's; ``release(y)`` offers a page-locked one back to the
+    pool for the next call (repeated workloads: page-locking 442 MB costs ~0.1 s, more than a warm pass)."""
 
-    def __init__(self, devices=(0,), backend=None, precision="f32"):
+    def __init__(self, devices=(0,), backend=None, precision="f32", pool_bytes=None):
         if backend is None:
             from . import engine as backend
         self.backend = backend
@@ -128,8 +314,8 @@ class PosteriorRunner:
         self.shards = _normalise_shards(devices)
         self.devices = [g for g, _ in self.shards]
         self._state = {}
-        self._pinned = {}            # (n, c) -> page-locked blocks handed out by _out
-        self._requests = {}          # (n, c) -> how often that shape has been asked for
+        self.pool = PinnedPool(getattr(backend, "pinned_empty", None), pool_bytes)
+        self._requests = 0
         self._lock = threading.Lock()
 
     def _dev(self, shard):
@@ -144,29 +330,20 @@ class PosteriorRunner:
             return st
 
     def _out(self, n, c):
-        """The gathered [N, C] array.  Page-locked when the backend offers it (am_host_alloc): every shard's download then
-        runs at PCIe rate straight into its slice, instead of being staged through the driver's bounce buffers.
-        Page-locking 442 MB costs ~0.1 s, more than a warm pass over a core-test-sized file, so the blocks are pooled: a block
-        is handed out again once nothing but the pool refers to it (the caller has dropped the array and every view of it)."""
-        alloc = getattr(self.backend, "pinned_empty", None)
-        if alloc is None or n * c == 0:
-            return np.empty((n, c), dtype=np.float32)
-        import sys
+        """The gathered [N, C] array of forward_ff / forward_lstm.  Page-locked (every shard's download then runs at PCIe
+        rate straight into its slice instead of through the driver's bounce buffers) -- except for the very first request
+        of a single-shard runner: a one-shot call is faster into pageable memory (43 ms for the core-test file) than into
+        memory it first has to page-lock (~100 ms); from the second request on the pool is used."""
         with self._lock:
-            seen = self._requests[(n, c)] = self._requests.get((n, c), 0) + 1
-            if len(self.shards) == 1 and seen == 1:
-                # one shard, first request of this shape: a one-shot call is faster into pageable memory (43 ms for the
-                # core-test file) than into memory it first has to page-lock (~100 ms); a repeated workload gets the pool
-                return np.empty((n, c), dtype=np.float32)
-            pool = self._pinned.setdefault((n, c), [])
-            for y in pool:
-                if sys.getrefcount(y) <= 3:      # the pool's list, the loop variable, getrefcount's argument
-                    return y
-            y = alloc((n, c), np.float32)
-            pool.append(y)
-            if len(pool) > 4:                    # callers that keep many results alive: stop pooling the oldest
-                pool.pop(0)
-            return y
+            self._requests += 1
+            first = self._requests == 1
+        if len(self.shards) == 1 and first:
+            return np.empty((n, c), dtype=np.float32)
+        return self.pool.take(n, c)
+
+    def release(self, y):
+        """Offer a result array back to the pool (no-op for pageable arrays).  ``y`` must not be used afterwards."""
+        return self.pool.give(y)
 
     def _configure(self, st, ensemble, D, shifts, ft, d_iv, prior, combine, normalise):
         specs = list(ensemble.members())
@@ -234,11 +411,11 @@ class PosteriorRunner:
         """x: [N, D] frames of whole utterances delimited by ``offsets``.  Returns float32 [N, C] in file order."""
         ens = as_ensemble(model)
         x = np.ascontiguousarray(x, dtype=np.float32)
-        offsets = np.asarray(offsets, dtype=np.int64)
         n, D = x.shape
+        offsets = check_offsets(offsets, n)   # every row then belongs to an utterance of some bin: all of y is overwritten
         iv = None if ivectors is None else np.ascontiguousarray(ivectors, dtype=np.float32)
         d_iv = 0 if iv is None else iv.shape[1]
-        y = self._out(n, ens.num_classes)   # every row belongs to an utterance of some bin: all of it is overwritten
+        y = self._out(n, ens.num_classes)
         bins = lstm_bins(offsets, len(self.shards))
         jobs = []
         for utts, shard in zip(bins, self.shards):
@@ -250,44 +427,92 @@ class PosteriorRunner:
                     return
                 xs, local = gather_utterances(x, offsets, utts)
                 ivs = None if iv is None else gather_utterances(iv, offsets, utts)[0]
-                ys = p.forward_lstm(xs, local, ivs, timedelay, out=self._out(xs.shape[0], ens.num_classes))
+                ys = p.forward_lstm(xs, local, ivs, timedelay, out=self.pool.take(xs.shape[0], ens.num_classes))
                 for j, u in enumerate(utts):
                     y[offsets[u]:offsets[u + 1]] = ys[local[j]:local[j + 1]]
+                self.pool.give(ys)            # a temporary of this call: straight back to the pool
             jobs.append((shard, job))
         if jobs:
             self._run_parallel(jobs)
         return y
 
-    # device-resident variants (single GPU): the posteriors stay in the pipeline's device memory -------------------
-    def resident(self, model, x, offsets=None, shifts=(0,), ft=None, ivectors=None, prior=None, recurrent=False, normalise=True):
-        """Upload + run without the download: returns the pipeline that now holds the [N, C] posteriors on the GPU
-        (``PhoneRecog.recognise_pipeline`` decodes them in place).  One shard only.  In split-f16 mode ``ff_run`` itself
-        repeats the pass on the exact f32 path when an activation does not fit f16 (am_ff_run)."""
-        if len(self.shards) != 1:
-            raise ValueError("device-resident posteriors need a single-GPU runner")
+    # every shard delivers its own rows ---------------------------------------------------------------
+    def map_shards(self, model, x, fn, offsets=None, shifts=(0,), ft=None, ivectors=None, prior=None, recurrent=False, timedelay=0,
+                   combine=AM_COMBINE_LOGITS, normalise=True):
+        """Run the pass shard by shard and call ``fn(ctx)`` (``ShardContext``) in each shard's thread once its posteriors are
+        on its GPU; -> the list of ``fn``'s return values in shard order.
+
+        Feed-forward with ``offsets``: frame ranges cut at utterance boundaries (``ff_shards_aligned``), so a shard owns whole
+        utterances; without: plain even ranges.  Recurrent: longest-first utterance bins.  Nothing is gathered: ``fn`` writes,
+        decodes or copies its shard's rows wherever they have to go (``ctx.download()`` for a host copy)."""
         ens = as_ensemble(model)
         x = np.ascontiguousarray(x, dtype=np.float32)
+        n, D = x.shape
         iv = None if ivectors is None else np.ascontiguousarray(ivectors, dtype=np.float32)
         d_iv = 0 if iv is None else iv.shape[1]
-        st = self._dev(self.shards[0])
-        shifts = [0] if recurrent else [int(s) for s in shifts]
-        p = self._configure(st, ens, x.shape[1], shifts, ft, d_iv, prior, AM_COMBINE_LOGITS, normalise)
+        if offsets is not None:
+            offsets = check_offsets(offsets, n)
+        if recurrent and offsets is None:
+            raise ValueError("recurrent networks need the utterance offsets")
+        results = [None] * len(self.shards)
+        jobs = []
         if recurrent:
-            p.lstm_upload(x, iv, np.asarray(offsets, dtype=np.int64), 0)
-            p.lstm_run()
+            bins = lstm_bins(offsets, len(self.shards))
+            for i, (utts, shard) in enumerate(zip(bins, self.shards)):
+                def job(i=i, utts=utts, shard=shard):
+                    st = self._dev(shard)
+                    p = self._configure(st, ens, D, [0], ft, d_iv, prior, combine, normalise)
+                    if len(bins) == 1:
+                        xs, local, ivs = x, offsets, iv
+                    else:
+                        xs, local = gather_utterances(x, offsets, utts)
+                        ivs = None if iv is None else gather_utterances(iv, offsets, utts)[0]
+                    p.lstm_upload(xs, ivs, local, timedelay)
+                    p.lstm_run()
+                    ctx = ShardContext(self, i, shard, st, True, utts, local, None, None, xs.shape[0])
+                    try:
+                        results[i] = fn(ctx)
+                    finally:
+                        ctx.release()
+                jobs.append((shard, job))
+            results = results[:len(bins)]
         else:
-            p.ff_upload(x, iv, x.shape[0], 0, 0)
-            p.ff_run()
-        return p
+            sh = [int(s) for s in shifts]
+            ctxw = max(abs(s) for s in sh)
+            if offsets is not None:
+                ranges = ff_shards_aligned(offsets, len(self.shards), ctxw)
+            else:
+                ranges = [r + (None, None) for r in ff_shards(n, len(self.shards), ctxw)]
+            for i, ((lo, hi, h_lo, h_hi, u_lo, u_hi), shard) in enumerate(zip(ranges, self.shards)):
+                def job(i=i, lo=lo, hi=hi, h_lo=h_lo, h_hi=h_hi, u_lo=u_lo, u_hi=u_hi, shard=shard):
+                    st = self._dev(shard)
+                    p = self._configure(st, ens, D, sh, ft, d_iv, prior, combine, normalise)
+                    p.ff_upload(x[lo - h_lo:hi + h_hi], None if iv is None else iv[lo:hi], hi - lo, h_lo, h_hi)
+                    p.ff_run()
+                    utts = None if u_lo is None else np.arange(u_lo, u_hi, dtype=np.int64)
+                    local = None if u_lo is None else offsets[u_lo:u_hi + 1] - lo
+                    ctx = ShardContext(self, i, shard, st, False, utts, local, lo, hi, hi - lo)
+                    try:
+                        results[i] = fn(ctx)
+                    finally:
+                        ctx.release()
+                jobs.append((shard, job))
+            results = results[:len(ranges)]
+        if jobs:
+            self._run_parallel(jobs)
+        return results
 
     def close(self):
         for st in self._state.values():
+            for d in st.decoders.values():
+                if hasattr(d, "close"):
+                    d.close()
             st.pipeline.close()
             for _, m in st.models:
                 m.close()
             st.engine.close()
         self._state = {}
-        self._pinned = {}
+        self.pool.clear()
 
 
 _default_runners = {}

@@ -98,6 +98,31 @@ class Pipeline:
             return out
         return y
 
+    # resident form (upload / run / download), as the product's Pipeline offers it
+    def ff_upload(self, x_ext, ivec, n, halo_lo, halo_hi):
+        self._job = ("ff", np.array(x_ext, np.float32), None if ivec is None else np.array(ivec, np.float32), n, halo_lo, halo_hi)
+        self._res = None
+
+    def ff_run(self):
+        _, x_ext, ivec, n, h_lo, h_hi = self._job
+        self._res = self.forward_ff(x_ext, ivec, n, h_lo, h_hi)
+
+    def ff_download(self, out=None):
+        if out is not None:
+            out[...] = self._res
+            return out
+        return self._res.copy()
+
+    def lstm_upload(self, x, ivec, offsets, timedelay=0):
+        self._job = ("lstm", np.array(x, np.float32), None if ivec is None else np.array(ivec, np.float32), np.array(offsets), timedelay)
+        self._res = None
+
+    def lstm_run(self):
+        _, x, ivec, offsets, timedelay = self._job
+        self._res = self.forward_lstm(x, offsets, ivec, timedelay)
+
+    lstm_download = ff_download
+
     def forward_lstm(self, x, offsets, ivec=None, timedelay=0, out=None):
         feats = x if self.ft is None else orc.apply_feature_transform(x, self.ft)
         if ivec is not None:

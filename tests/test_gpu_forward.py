@@ -342,7 +342,7 @@ def test_split_f16_precision_mode(engine, real_ft_path, real_priors):
         assert np.all(np.isfinite(res_b)) and np.max(np.abs(res_b - want_b)) <= TOL
         got_b = pb.forward_ff(x)   # one-shot call: automatic exact re-run too
         assert pb.overflowed() and np.array_equal(got_b, res_b)
-        # evaluate --no-lab: PosteriorRunner.resident() hands the pipeline to the in-place decoder without a download;
+        # evaluate --no-lab: PosteriorRunner.map_shards() hands each shard's pipeline to the in-place decoder without a download;
         # with overflowing activations the decoded posteriors must be the exact path's
         from nnacousticmodeling_amd import networks, sharding
         from nnacousticmodeling_amd.phone_recog import PhoneRecog
@@ -353,12 +353,13 @@ def test_split_f16_precision_mode(engine, real_ft_path, real_priors):
         runner = sharding.PosteriorRunner([0], precision="split_f16")
         try:
             spec_b = networks.get_nn("ff", 4, [1024], 1909).set_params(big)
-            pr = runner.resident(spec_b, x, offs, shifts=ft["shifts"], ft=ft)
-            assert pr.overflowed()
-            dec = PhoneRecog(pr.engine, gdict, -4.0, 1.0)
-            segs = dec.recognise_pipeline(pr, offs)
-            assert np.array_equal(pr.ff_download(), res_b)
-            dec.close()
+            def on_shard(ctx):
+                assert ctx.pipeline.overflowed()
+                dec = ctx.decoder("viterbi", lambda eng_: PhoneRecog(eng_, gdict, -4.0, 1.0))
+                got = dec.recognise_pipeline(ctx.pipeline, ctx.local_offsets)
+                assert np.array_equal(ctx.download(), res_b)
+                return got
+            (segs,) = runner.map_shards(spec_b, x, on_shard, offsets=offs, shifts=ft["shifts"], ft=ft)
         finally:
             runner.close()
         dec2 = PhoneRecog(engine, gdict, -4.0, 1.0)

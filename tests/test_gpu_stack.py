@@ -61,7 +61,9 @@ def test_stack_equals_per_layer_launches(engine, real_ft_path, monkeypatch, laye
     ref, prof0 = _stack_launches(engine, p, x, iv)
     assert "gemm_stack" not in prof0 and prof0["gemm_hidden"][0] >= layers, prof0
     assert np.array_equal(ref, y)
-    assert np.array_equal(p.forward_ff(x, iv), y)   # the one-shot pipelined path (16,384-row chunks, per-layer launches)
+    assert np.array_equal(p.forward_ff(x, iv), y)   # the one-shot pipelined path (16,384-row chunks; AM_FF_STACK is still 0 here: per-layer launches)
+    monkeypatch.setenv("AM_FF_STACK", "1")
+    assert np.array_equal(p.forward_ff(x, iv), y)   # ... and in its default form: one stack launch per chunk (am_api.hip ff_run_chunks)
     rows = np.unique(np.concatenate([np.arange(0, 4), np.arange(n - 4, n), rng.integers(0, n, 24)]))
     feats = orc.apply_feature_transform(orc.prepare_batch(x, rows, 11), ft)
     if iv is not None:

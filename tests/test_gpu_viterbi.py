@@ -217,6 +217,25 @@ def test_evaluate_end_to_end_with_gpu_decoder(engine, tmp_path, real_ft_path, re
     assert per2 == per
     assert (lab2 / "vysledek_test.txt").read_text().replace(str(lab2), str(lab_dir)) == mlf_with_lab
     assert not list(lab2.glob("*.lab"))
+    # ... and on several shards (three engines on this one card stand in for three GPUs): every shard decodes its own utterances
+    # from its own device memory and writes its own .lab files; same MLF, same PER, same .lab bytes (rows do not depend on the shard)
+    from nnacousticmodeling_amd import networks
+    from nnacousticmodeling_amd.evaluate_model_for_test import evaluateModelTestTri
+    spec = networks.get_nn("ff", 2, [128], 1909).set_params(params)
+    shifts = list(range(-5, 6))
+    for tag, write_lab in (("lab_sharded", True), ("lab_sharded_nolab", False)):
+        lab3 = tmp_path / tag
+        per3 = evaluateModelTestTri(spec, x, off, 3, 0.5, ap=real_priors, GPUID=[(0, 0), (0, 1), (0, 2)], testOrDev="test", tmpDir=str(lab3),
+                                    uttlistdir=str(data_dir), recogdir=str(recog_dir), progress=False, frontend=(shifts, ft), run_decoder="gpu",
+                                    write_lab=write_lab)
+        assert per3 == per
+        assert (lab3 / "vysledek_test.txt").read_text().replace(str(lab3), str(lab_dir)) == mlf_with_lab
+        if write_lab:
+            for nm in names:
+                assert (lab3 / (nm + ".lab")).read_bytes() == (lab_dir / (nm + ".lab")).read_bytes()
+            assert (lab3 / "test.scp").read_text().replace(str(lab3), str(lab_dir)) == (lab_dir / "test.scp").read_text()
+        else:
+            assert not list(lab3.glob("*.lab"))
     # decoding straight from device memory gives the same segmentation as decoding the downloaded posteriors
     from nnacousticmodeling_amd.engine import Model, Pipeline
     p = Pipeline(engine)

