@@ -224,6 +224,10 @@ int am_lstm_persist_enabled(int device);
 int am_lstm_persist_reenable(int device);
 int am_pipeline_recurrent_form(am_pipeline* p, int* n_persistent, int* n_members);
 
+/* Wait for everything the pipeline has enqueued and make sure its resident posteriors are valid: a persistent launch that gave
+ * up on a bounded wait is repeated on the per-step / per-layer kernels here (as am_*_download and am_decode_pipeline do).  Callers
+ * that time am_ff_run / am_lstm_run loops without downloading call this once after the loop and compare am_lstm_fallback_count(). */
+int am_pipeline_synchronize(am_pipeline* p);
 /* number of frames / classes of the resident output (after *_upload) */
 int am_pipeline_output_shape(am_pipeline* p, int64_t* n, int* c);
 

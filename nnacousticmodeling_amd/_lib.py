@@ -71,6 +71,7 @@ SIGNATURES = {
     "am_lstm_persist_enabled": (C.c_int, [C.c_int]),
     "am_lstm_persist_reenable": (C.c_int, [C.c_int]),
     "am_pipeline_recurrent_form": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
+    "am_pipeline_synchronize": (C.c_int, [C.c_void_p]),
     "am_pipeline_output_shape": (C.c_int, [C.c_void_p, c_int64_p, c_int_p]),
     "am_frontend_apply": (C.c_int, [C.c_void_p, c_float_p, c_float_p, C.c_int64, C.c_int, C.c_int, c_float_p]),
     "am_lognormalise": (C.c_int, [C.c_void_p, c_float_p, C.c_int64, C.c_int, c_float_p]),

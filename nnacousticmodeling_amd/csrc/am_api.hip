@@ -1868,6 +1868,19 @@ extern "C" int am_forward_lstm(am_pipeline* p, const float* x, const float* ivec
     return am_lstm_download(p, y);
 }
 
+extern "C" int am_pipeline_synchronize(am_pipeline* p)
+{
+    if (!p) return fail(AM_EINVAL, "pipeline is NULL");
+    am_engine* e = p->e;
+    HIP_TRY(hipSetDevice(e->device));
+    AM_TRY(join_streams(e));
+    AM_TRY(sync_all(e));
+    if (!p->results_valid) return AM_OK;
+    if (p->mode == 2 && p->used_persist) AM_TRY(persist_check(p));
+    if (p->mode == 1 && p->used_stack) AM_TRY(ff_stack_check(p));
+    return AM_OK;
+}
+
 extern "C" int am_pipeline_output_shape(am_pipeline* p, int64_t* n, int* c)
 {
     if (!p || p->mode == 0 || !n || !c) return fail(AM_EINVAL, "am_pipeline_output_shape: nothing uploaded");

@@ -331,6 +331,10 @@ class Pipeline:
     def set_normalise(self, on):
         check(self._lib.am_pipeline_set_normalise(self._h, 1 if on else 0))
 
+    def synchronize(self):
+        """Wait for the enqueued passes and make sure the resident posteriors are valid (am_pipeline_synchronize)."""
+        check(self._lib.am_pipeline_synchronize(self._h))
+
     # feed-forward ----------------------------------------------------------------------------------
     def ff_upload(self, x_ext, ivec, n, halo_lo, halo_hi):
         x_ext = _f32(x_ext)
