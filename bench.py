@@ -364,24 +364,26 @@ def secondary_records(eng, ft, params, layers, x, steps):
     t0 = time.perf_counter()
     res = dec.recognise(z, off)
     host_s = time.perf_counter() - t0
+    pass_ms = eng.elapsed_ms(62, 63)   # device time of the un-instrumented pass: first launch -> last launch done (am_decode_* records both)
     eng.profile(True)
     eng.profile_reset()
     dec.recognise(z, off)
     vprof = eng.profile_read()
     eng.profile(False)
-    vit_ms = vprof["viterbi"][1]
+    vit_ms = pass_ms                   # the roofline figure: the whole pass as it runs in production, launch gaps included
     steps_v = int(np.diff(off).max())
     # HBM bytes the pass cannot avoid: per (utterance, frame) the state of every triphone read (20 B) and written (24 B), the node
     # back-pointers (8 B) and the frame's posterior row; per frame-launch the graph constants once (32 B per triphone, shared by all
     # utterances of the launch: L2 / Infinity Cache serve the repeats)
     vit_bytes = n57 * (T_ * 44 + B_ * 8 + 1909 * 4) + steps_v * T_ * 32
-    out["viterbi_realsize"] = {"value": n57 / (vit_ms * 1e-3), "unit": "frames/s (kernel time)", "kernel_ms": vit_ms, "launches": vprof["viterbi"][0],
+    out["viterbi_realsize"] = {"value": n57 / (vit_ms * 1e-3), "unit": "frames/s (device time of the pass)", "pass_ms": vit_ms,
+                               "kernel_ms_sum_with_an_event_pair_per_launch": vprof["viterbi"][1], "launches": vprof["viterbi"][0],
                                "host_array_to_segments_s": host_s, "frames": n57, "utterances": 192, "segments": sum(len(r) for r in res),
                                "graph": {"phones": 48, "nodes": B_, "triphones": T_, "states": 1909},
                                "roofline": {"bound": "hbm", "kernel": "viterbi_fs_tri_kernel + viterbi_fs_node_kernel (one launch pair per frame over all active utterances)",
                                             "achieved": vit_bytes / (vit_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": vit_bytes / (vit_ms * 1e-3) / 8e12,
                                             "algorithmic_bytes": vit_bytes,
-                                            "measured": "HIP events around every launch (host-paced: ~2 x 614 launches)"}}
+                                            "measured": "one HIP event pair around the pass's launch sequence on the engine's compute stream"}}
     dec.close()
     del z
     return out
@@ -414,10 +416,10 @@ def product_host_to_host(n_devices, ft, params, layers, x):
         def keep(ctx):
             return ctx.download().shape[0]
         for _ in range(2):
-            runner.map_shards(spec, x, keep, **kw)
+            runner.map_shards(spec, x, keep, host=True, **kw)
         t0 = time.perf_counter()
         for _ in range(reps):
-            rows = runner.map_shards(spec, x, keep, **kw)
+            rows = runner.map_shards(spec, x, keep, host=True, **kw)
         dt = (time.perf_counter() - t0) / reps
         assert sum(rows) == n
         out["per_shard_blocks"] = {"value": n / dt, "unit": "frames/s", "ms_per_pass": dt * 1e3}

@@ -73,7 +73,7 @@ int am_pipeline_overflowed(am_pipeline* p, int* flag);   /* synchronises; flag =
 
 /* HIP events on the engine's compute stream (the stream every kernel below is launched on).
  * slot in [0, 64).  Used by bench.py for the timed region. */
-int am_event_record(am_engine* e, int slot);
+int am_event_record(am_engine* e, int slot);   /* (slots 62 and 63 are recorded by am_decode_* around its launch sequence) */
 int am_event_elapsed_ms(am_engine* e, int slot_start, int slot_stop, float* ms); /* synchronises on slot_stop */
 
 /* Per-kernel timing: when on, every kernel launch is bracketed by a HIP event pair on the compute stream.

@@ -102,7 +102,7 @@ def evaluateModelTestTri(model, data, offsets, PIP, LMW, ap=None, GPUID=0, testO
 
     runner = get_runner(devices)
     shard_results = runner.map_shards(as_ensemble(model), data, per_shard, offsets=offsets, shifts=shifts, ft=ft, ivectors=ivectors,
-                                      prior=ap, recurrent=rnn, timedelay=0)
+                                      prior=ap, recurrent=rnn, timedelay=0, host=need_lab)
     scp = Path(labDirOut, testOrDev + ".scp")
     if need_lab:
         if progress:

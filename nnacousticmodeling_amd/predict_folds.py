@@ -68,7 +68,7 @@ def predict_to_npy(path, model, x, offsets, num_classes, network, gpu, winlen, t
     winhalf = int(winlen / 2)
     shifts = [0] if recurrent else range(-winhalf, winhalf + 1)
     runner.map_shards(model, x, per_shard, offsets=offsets if recurrent else None, shifts=shifts, ft=ft, recurrent=recurrent,
-                      timedelay=timedelay, combine=combine)
+                      timedelay=timedelay, combine=combine, host=True)
     out.flush()
     del out
     return path

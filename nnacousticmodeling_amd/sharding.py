@@ -438,13 +438,15 @@ class PosteriorRunner:
 
     # every shard delivers its own rows ---------------------------------------------------------------
     def map_shards(self, model, x, fn, offsets=None, shifts=(0,), ft=None, ivectors=None, prior=None, recurrent=False, timedelay=0,
-                   combine=AM_COMBINE_LOGITS, normalise=True):
+                   combine=AM_COMBINE_LOGITS, normalise=True, host=False):
         """Run the pass shard by shard and call ``fn(ctx)`` (``ShardContext``) in each shard's thread once its posteriors are
         on its GPU; -> the list of ``fn``'s return values in shard order.
 
         Feed-forward with ``offsets``: frame ranges cut at utterance boundaries (``ff_shards_aligned``), so a shard owns whole
         utterances; without: plain even ranges.  Recurrent: longest-first utterance bins.  Nothing is gathered: ``fn`` writes,
-        decodes or copies its shard's rows wherever they have to go (``ctx.download()`` for a host copy)."""
+        decodes or copies its shard's rows wherever they have to go (``ctx.download()`` for a host copy).  ``host=True`` says the
+        host copy will be wanted: feed-forward shards then run the pipelined form (the download of chunk c beside the compute of
+        chunk c + 1, am_forward_ff) straight into the shard's block; the posteriors stay resident on the GPU as well."""
         ens = as_ensemble(model)
         x = np.ascontiguousarray(x, dtype=np.float32)
         n, D = x.shape
@@ -487,11 +489,15 @@ class PosteriorRunner:
                 def job(i=i, lo=lo, hi=hi, h_lo=h_lo, h_hi=h_hi, u_lo=u_lo, u_hi=u_hi, shard=shard):
                     st = self._dev(shard)
                     p = self._configure(st, ens, D, sh, ft, d_iv, prior, combine, normalise)
-                    p.ff_upload(x[lo - h_lo:hi + h_hi], None if iv is None else iv[lo:hi], hi - lo, h_lo, h_hi)
-                    p.ff_run()
                     utts = None if u_lo is None else np.arange(u_lo, u_hi, dtype=np.int64)
                     local = None if u_lo is None else offsets[u_lo:u_hi + 1] - lo
                     ctx = ShardContext(self, i, shard, st, False, utts, local, lo, hi, hi - lo)
+                    if host:
+                        ctx._host = p.forward_ff(x[lo - h_lo:hi + h_hi], None if iv is None else iv[lo:hi], hi - lo, h_lo, h_hi,
+                                                 out=self._out(hi - lo, ens.num_classes))
+                    else:
+                        p.ff_upload(x[lo - h_lo:hi + h_hi], None if iv is None else iv[lo:hi], hi - lo, h_lo, h_hi)
+                        p.ff_run()
                     try:
                         results[i] = fn(ctx)
                     finally:

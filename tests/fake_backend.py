@@ -93,6 +93,7 @@ class Pipeline:
         if ivec is not None:
             feats = np.concatenate((feats, ivec), axis=1)
         y = self._finish(lambda net: net(feats), n)
+        self._res = y     # (resident, as after am_forward_ff)
         if out is not None:
             out[...] = y
             return out
