@@ -98,7 +98,6 @@ struct Layer {
     int in = 0, out = 0, in_pad = 0, out_pad = 0;
     int U = 0, U_pad = 0;  // LSTM layers only
     DevBuf W, b, Wlat;
-    DevBuf W_um, b_um;     // LSTM layer 0 only: upward weights / bias with the rows of a 16-unit tile in unit-major order (lstm_persist4_kernel's G)
     // split-f16 precision mode (feed-forward only), built on first use
     float wmax = 0.f;      // max |W| (host scan at creation)
     float w_scale = 1.f;   // exact power of two applied to W before splitting
@@ -163,7 +162,7 @@ struct am_pipeline {
     int timedelay = 0;
     // persistent form of the LSTM stack (lstm_persist_kernel): per member the group plan + arrival table, shared step tables
     struct PersistPlan {
-        int form = 0;                       // 0 per-step kernels, 1 lstm_persist_kernel, 2 lstm_persist4_kernel
+        int form = 0;                       // 0 per-step kernels, 1 lstm_persist_kernel
         std::vector<LstmPersistArgs> chunks;   // one launch per chunk of utterance slots (utterances are independent; longest first)
         std::vector<DevBuf> cums;
         void release() { for (auto& c : cums) c.release(); cums.clear(); chunks.clear(); form = 0; }
@@ -552,17 +551,6 @@ extern "C" int am_model_create(am_engine* e, int kind, int n_layers, int activat
             if ((rc = upload(e, Ly.W, w)) != AM_OK) break;
             if ((rc = upload(e, Ly.b, bb)) != AM_OK) break;
             if ((rc = upload(e, Ly.Wlat, wl)) != AM_OK) break;
-            if (l == 0) {   // the same rows, unit-major inside each 16-unit tile: the hoisted GEMM then writes G as the 4 x 512-register persistent kernel reads it
-                std::vector<float> wm((size_t)Ly.out_pad * Ly.in_pad, 0.f), bm(Ly.out_pad, 0.f);
-                for (int u = 0; u < Ly.U; ++u)
-                    for (int k = 0; k < 4; ++k) {
-                        const int src = 4 * u + k, dst = (u / 16) * 64 + 4 * (u % 16) + k;
-                        memcpy(&wm[(size_t)dst * Ly.in_pad], W[l] + (size_t)src * Ly.in, sizeof(float) * Ly.in);
-                        bm[dst] = b[l][src];
-                    }
-                if ((rc = upload(e, Ly.W_um, wm)) != AM_OK) break;
-                if ((rc = upload(e, Ly.b_um, bm)) != AM_OK) break;
-            }
             m->max_width = std::max(m->max_width, Ly.U_pad);
         } else {
             Ly.out_pad = gemm_n_pad(Ly.out);
@@ -586,7 +574,7 @@ extern "C" int am_model_destroy(am_model* m)
     if (!m) return AM_OK;
     (void)hipSetDevice(m->e->device);
     for (auto& l : m->L) {
-        l.W.release(); l.b.release(); l.Wlat.release(); l.Whi.release(); l.Wlo.release(); l.b_s.release(); l.W_um.release(); l.b_um.release();
+        l.W.release(); l.b.release(); l.Wlat.release(); l.Whi.release(); l.Wlo.release(); l.b_s.release();
         l.WA.release(); l.WB.release(); l.bA_first.release(); l.bA_rest.release(); l.bB_first.release(); l.bB_rest.release();
     }
     am_engine* e = m->e;
@@ -1522,14 +1510,8 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
             if (!fits) continue;
             auto& pl = p->persist[mi];
             const int U_pad = m->L[0].U_pad;
-            int form = pmode == 1 ? 1 : 2;
-            int max_wgs = lstm_persist_resident_wgs(U_pad, e->n_cus, form);
-            int cap = lstm_persist_capacity(U_pad, m->n_layers, max_wgs, form);
-            if (cap <= 0 && form == 2) {   // (a toolchain whose build of the 4 x 512-register form spills: the first form instead)
-                form = 1;
-                max_wgs = lstm_persist_resident_wgs(U_pad, e->n_cus, form);
-                cap = lstm_persist_capacity(U_pad, m->n_layers, max_wgs, form);
-            }
+            const int max_wgs = lstm_persist_resident_wgs(U_pad, e->n_cus);
+            const int cap = lstm_persist_capacity(U_pad, m->n_layers, max_wgs);
             if (cap <= 0) continue;
             bool ok = true;
             for (int base = 0; base < n_utts && ok; base += cap) {
@@ -1546,7 +1528,7 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
                 HIP_TRY(hipMemcpyAsync(pl.cums.back().p, staging.back().data(), sizeof(unsigned) * staging.back().size(), hipMemcpyHostToDevice, e->stream));
                 pl.chunks.push_back(pa);
             }
-            if (ok) { pl.form = form; any_persist = true; } else pl.release();
+            if (ok) { pl.form = 1; any_persist = true; } else pl.release();
         }
         AM_TRY(sync_all(e));   // the staging vectors go out of scope here
     }
@@ -1579,7 +1561,7 @@ extern "C" int am_pipeline_recurrent_form(am_pipeline* p, int* n_persistent, int
     if (!p || !n_persistent || !n_members || p->mode != 2) return fail(AM_EINVAL, "am_pipeline_recurrent_form: nothing uploaded (am_lstm_upload)");
     *n_members = (int)p->members.size();
     *n_persistent = 0;
-    for (auto& pl : p->persist) *n_persistent += pl.form != 0;
+    for (auto& pl : p->persist) *n_persistent += pl.form == 1;
     return AM_OK;
 }
 
@@ -1619,7 +1601,7 @@ extern "C" int am_lstm_run(am_pipeline* p)
     // graph serialises the second stream's branch (measured: 10.2 ms replayed against 8.8 ms eager)
     // (and a pass with a persistent launch in it waits for another engine's event, which a stream capture does not admit)
     bool any_persistent = false;
-    for (auto& pl : p->persist) any_persistent = any_persistent || pl.form != 0;
+    for (auto& pl : p->persist) any_persistent = any_persistent || pl.form == 1;
     if (e->profile || any_persistent || !lstm_use_graph()) return eager();   // per-kernel events need eager launches
     if (p->graph_exec) { HIP_TRY(hipGraphLaunch(p->graph_exec, e->stream)); return AM_OK; }
     if (p->lstm_runs++ == 0) return eager();          // one-shot use: eager (no capture / instantiate cost)
@@ -1745,8 +1727,7 @@ static int lstm_enqueue(am_pipeline* p)
         {
             Layer& L0 = m->L[0];
             GemmArgs g{};
-            const bool um = p->persist[mi].form == 2;   // lstm_persist4_kernel reads G unit-major
-            g.A = p->d_in.as<float>(); g.lda = m->in_pad; g.W = (um ? L0.W_um : L0.W).as<float>(); g.ldw = L0.in_pad; g.bias = (um ? L0.b_um : L0.b).as<float>();
+            g.A = p->d_in.as<float>(); g.lda = m->in_pad; g.W = L0.W.as<float>(); g.ldw = L0.in_pad; g.bias = L0.b.as<float>();
             g.C = p->d_G.as<float>(); g.ldc = L0.out_pad; g.M_pad = (int)rows_pad; g.N_pad = L0.out_pad;
             // the input plane is padded to 128 columns for the recurrent kernels' k batches; the columns past the real input are zeros on
             // both sides, so the product stops at the GEMM's own k step (40 inputs: 64 instead of 128 -- half the launch, the same bits)
@@ -1756,8 +1737,7 @@ static int lstm_enqueue(am_pipeline* p)
         }
         float* Hall = p->d_H.as<float>();
         float* Call = p->d_c.as<float>();
-        if (p->persist[mi].form != 0) {
-            const int pform = p->persist[mi].form;
+        if (p->persist[mi].form == 1) {
             float* Cplanes = p->d_cplane.as<float>();
             // the whole stack and time axis in one persistent launch per chunk of utterance slots (lstm_persist_kernel)
             static const bool want_stamps = env_int("AM_LSTM_STAMPS", 0) != 0;
@@ -1802,25 +1782,26 @@ static int lstm_enqueue(am_pipeline* p)
                     PersistGate& G = gate_of(e);
                     std::lock_guard<std::mutex> lk(G.mu);
                     if (G.last && G.owner != e) HIP_TRY(hipStreamWaitEvent(e->stream, G.last, 0));
-                    if (split_rows > 0 && pform == 2) {
-                        // The second form fills every SIMD's register file (4 waves x 512): no other wave fits beside it, so a spinning
-                        // gate kernel that reached a CU first would keep one of its workgroups out for good.  Instead the time axis is cut
-                        // at the step from which <= 32 utterances run: the launch for the steps before it ends there (an event the second
-                        // stream waits for -- nothing spins), the launch for the rest finds the arrival counters where the first one left
-                        // them: at their values after the step before (~10 us for the boundary and the weights' reload, once per pass).
+                    if (split_rows > 0) {
+                        // The output layer of the finished rows runs beside the recurrence's tail.  The time axis is cut at the step from
+                        // which <= 32 utterances run: the launch for the steps before it ends there -- an event the second stream waits
+                        // for; nothing spins on the GPU, so nothing can sit on a CU the recurrence needs -- and the launch for the rest
+                        // finds h, c and the arrival counters where the first one left them (~10 us for the boundary and the weights'
+                        // reload, once per pass).  (Rounds 1-2 ran ONE launch and a one-wave gate kernel polling its counters in front
+                        // of the GEMM: that wave had to find room beside a workgroup of the recurrence on some SIMD, which happened to
+                        // work with this kernel's 2 x 248 registers and deadlocked into the 2-s bound with a kernel that fills the file.)
                         LstmPersistArgs head = pa, tail = pa;
                         head.t_begin = 0; head.t_end = (int)split_step;
                         tail.t_begin = (int)split_step; tail.t_end = pa.T;
-                        AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_persist(e->stream, head, pform); }));
+                        AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_persist(e->stream, head); }));
                         HIP_TRY(hipEventRecord(p->ev_fork, e->stream));             // (re-recorded: the second stream's branch starts here)
                         HIP_TRY(hipStreamWaitEvent(e->stream2, p->ev_fork, 0));
-                        AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_persist(e->stream, tail, pform); }));
+                        AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_persist(e->stream, tail); }));
                     } else
-                    AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_persist(e->stream, pa, pform); }));
+                    AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_persist(e->stream, pa); }));
                     HIP_TRY(hipEventRecord(e->persist_done, e->stream));
                     G.last = e->persist_done; G.owner = e;
                 }
-                if (split_rows > 0 && pform != 2) AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_gate(e->stream2, pa, NL - 1, (int)split_step - 1); }, e->stream2));
             }
             p->used_persist = true;
         } else

@@ -146,7 +146,6 @@ hipError_t launch_lstm_wavefront(hipStream_t s, LstmWavefrontArgs& a);
 // agent-scope (sc1) stores + per-group arrival counters instead of kernel boundaries.
 struct LstmPersistLayer {
     const float* G;      // layer 0: hoisted upward pre-activations (+bias) [NP, 4*U_pad], time-major packed; else nullptr
-                         // (form 1: gate-tiled columns 64 (u/16) + 16 gate + u%16; form 2: unit-major 64 (u/16) + 4 (u%16) + gate)
     const float* bias;   // layers >= 1: [4*U_pad] gate-tiled
     const float* Wup;    // layers >= 1: [4*U_pad, U_pad] gate-tiled rows
     const float* Wlat;   // [4*U_pad, U_pad] gate-tiled rows
@@ -159,8 +158,8 @@ struct LstmPersistLayer {
 struct LstmPersistArgs {
     LstmPersistLayer L[LSTM_MAX_LAYERS];
     int n_layers, U_pad, T;
-    int t_begin, t_end;            // lstm_persist4_kernel: the steps [t_begin, t_end) of this launch (0: t_end = T).  A launch that starts at
-                                   // t_begin > 0 finds the arrival counters as the launch for the steps before it left them
+    int t_begin, t_end;            // the steps [t_begin, t_end) of this launch (t_end == 0: up to T).  A launch that starts at t_begin > 0 finds h, c and
+                                   // the arrival counters as the launch for the steps before it left them
     int n_groups_total;            // grid = n_groups_total * (U_pad / 16)
     int max_wgs;                   // workgroups of this kernel the device holds at once (lstm_persist_resident_wgs): the plan's budget
     int slot_base, slot_cap;       // this launch covers the utterance slots [slot_base, slot_base + slot_cap) (longest first: a chunk of a larger file)
@@ -175,13 +174,11 @@ struct LstmPersistArgs {
 // stack does not fit the persistent form (then the per-step kernels run).  cum_out: [n_groups_total][T] arrival targets.
 bool plan_lstm_persist(LstmPersistArgs& a, int n_slots, const int* n_active_host, unsigned* cum_out /*nullable*/);
 size_t lstm_persist_cum_size(const LstmPersistArgs& a);   // entries of `cum`
-// form: 1 = lstm_persist_kernel (8 waves x 256 registers), 2 = lstm_persist4_kernel (4 x 512; layer 0's G in unit-major column order)
-int lstm_persist_resident_wgs(int U_pad, int n_cus, int form);      // co-resident workgroups of the kernel on a device of n_cus CUs (0: none)
-int lstm_persist_capacity(int U_pad, int n_layers, int max_wgs, int form);   // utterance slots one launch can take (0: this shape has no persistent form)
-hipError_t launch_lstm_persist(hipStream_t s, const LstmPersistArgs& a, int form);
-hipError_t launch_lstm_gate(hipStream_t s, const LstmPersistArgs& a, int layer, int tcol);   // returns once `layer` has finished step tcol
+int lstm_persist_resident_wgs(int U_pad, int n_cus);      // co-resident workgroups of the kernel on a device of n_cus CUs (0: none)
+int lstm_persist_capacity(int U_pad, int n_layers, int max_wgs);   // utterance slots one launch can take (0: this shape has no persistent form)
+hipError_t launch_lstm_persist(hipStream_t s, const LstmPersistArgs& a);
 
-int lstm_persist_mode();   // AM_LSTM_PERSIST: 0 per-step kernels, 1 the first persistent form, 2 (default) the second
+int lstm_persist_mode();   // AM_LSTM_PERSIST: 0 per-step kernels, 1 (default) the persistent form
 
 // Recurrent cells other than L.LSTM (GRU / MGRU / peephole LSTM): one phase of one wavefront tick, see rec_step_kernel.
 enum RecEpilogue {

@@ -1800,10 +1800,13 @@ __device__ __forceinline__ void persist_body(const LstmPersistArgs& a, const Lst
         }
     }
     auto local_rows = [&](int n) { n -= a.slot_base; return n < 0 ? 0 : (n > a.slot_cap ? a.slot_cap : n); };   // this launch's share of the active slots
-    int n_next = local_rows(a.n_active[0]);
-    for (int t = 0; t < a.T; ++t) {
+    // this launch's steps [t_begin, t_end): a launch that starts at t_begin > 0 finds h, c and the arrival counters as the launch for the steps
+    // before it left them (its first waits are already satisfied)
+    const int t_end = a.t_end > 0 ? a.t_end : a.T;
+    int n_next = local_rows(a.n_active[a.t_begin]);
+    for (int t = a.t_begin; t < t_end; ++t) {
         const int n_act = n_next;
-        n_next = t + 1 < a.T ? local_rows(a.n_active[t + 1]) : 0;   // requested a whole step ahead: the scalar load's latency is off the chain
+        n_next = t + 1 < t_end ? local_rows(a.n_active[t + 1]) : 0;   // requested a whole step ahead: the scalar load's latency is off the chain
         const int tiles = (n_act + 15) >> 4;
         if (tiles <= 0) break;
         const int q = (tiles + NG - 1) / NG;            // <= NTMAX (host plan)
@@ -1848,601 +1851,20 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_kernel(const LstmPersistA
 }
 
 
-// ---------------------------------------------------------------------------------------------------
-// The persistent recurrent kernel, second form ("p4", round 3): 4 waves x 512 registers instead of 8 x 256.
-//
-// Why: the first form (lstm_persist_kernel above) spends 21.4 us per 192-row step of an upper layer for 13.7 us of MFMA time.
-// Its timeline: each of the two products starts cold (its tiles can only be requested once the hand-off has arrived: ~1.2 us
-// each), the gates of a unit live in four waves and meet through LDS (0.8 us), and every attempt to overlap the products ran
-// into the register file: 128 VGPRs of weights per wave left 6 spare.  The weights are half of the CU's register file however
-// they are cut -- but cut into FOUR waves of 512 registers (one per SIMD: 256 of weights, 256 for everything else) instead of
-// eight of 256 (128 + 128), the per-wave state (addresses, fragments, both K halves' accumulators) is paid four times, not
-// eight, and there is room for what the first form could not hold:
-//   * ONE tile stream over both products and across the step boundary: with the ring's 4 buffers, tile i + 3 of the stream
-//     U(t) L(t) U(t+1) L(t+1) ... is requested at the boundary of tile i as soon as its dependency allows: the lateral tiles fly
-//     while the upward product is multiplied and -- when the layer below has already published step t + 1 -- the next step's
-//     upward tiles fly during the lateral product, the gates and the publish.  Neither product starts cold in the steady state;
-//   * a wave owns 4 units x 4 gates (MFMA operands swapped: the weights are the row operand), so a lane ends up with the four
-//     gate pre-activations of ONE (utterance, unit): the cell update happens in registers, no exchange between waves;
-//   * both K halves of a column are accumulated by the same wave, in separate chains, and added at the end: the summation
-//     order of the per-step kernels and of the first form, bit for bit.
-// Roles, hand-off protocol (sc1 stores + per-group arrival counters), row-group re-cut per step, time-major H and C planes,
-// bounded waits: as in the first form; the host plan (plan_lstm_persist) is shared.  Layer 0 reads its hoisted upward term G in
-// a unit-major layout (column 64 (u / 16) + 4 (u % 16) + gate), so that a lane's four gates are one 16-B load.
-// Landing waits are counted at run time: every wave keeps the number of LDS-DMA instructions it has issued (`iss`) and, per ring
-// buffer, the value of that count after the buffer's tile (`mark`); tile p has landed once at most iss - mark[p] of the wave's
-// vector-memory operations are outstanding (they complete in order; other loads and stores in between only make the wait
-// stricter).  The next step's tiles have that step's row count, so the number is not a compile-time constant.
-// ---------------------------------------------------------------------------------------------------
-constexpr int P4_THREADS = 256;
-constexpr int P4_SLD = 20;                                        // staging row stride (floats): 16 units + 16 B, as PERSIST_SGLD
-constexpr size_t P4_RING_UP = 4 * 64 * PERSIST_TILE_LD * sizeof(float);    // upper layers: 4 buffers x 64 rows  = 131,072 B
-constexpr size_t P4_RING_L0 = 3 * 96 * PERSIST_TILE_LD * sizeof(float);    // layer 0:      3 buffers x 96 rows  = 147,456 B
-constexpr size_t P4_STAGE = 2 * 96 * P4_SLD * sizeof(float);              // h and c on their way out: 15,360 B
-constexpr size_t P4_LDS = P4_RING_L0 > P4_RING_UP + P4_STAGE ? P4_RING_L0 : P4_RING_UP + P4_STAGE;   // 147,456 B
-
-__host__ __device__ constexpr int p4_min(int x, int y) { return x < y ? x : y; }
-
-__device__ __forceinline__ void p4_wait_vmcnt_dyn(int k)   // k: wave-uniform, known only at run time
-{
-#define AM_P4_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-    switch (__builtin_amdgcn_readfirstlane(k)) {   // (scalar jump table: without it the compiler builds a divergent search over exec masks)
-    AM_P4_W(0) AM_P4_W(1) AM_P4_W(2) AM_P4_W(3) AM_P4_W(4) AM_P4_W(5) AM_P4_W(6) AM_P4_W(7) AM_P4_W(8) AM_P4_W(9)
-    AM_P4_W(10) AM_P4_W(11) AM_P4_W(12) AM_P4_W(13) AM_P4_W(14) AM_P4_W(15) AM_P4_W(16) AM_P4_W(17) AM_P4_W(18) AM_P4_W(19)
-    AM_P4_W(20) AM_P4_W(21) AM_P4_W(22) AM_P4_W(23) AM_P4_W(24) AM_P4_W(25) AM_P4_W(26) AM_P4_W(27) AM_P4_W(28) AM_P4_W(29)
-    AM_P4_W(30) AM_P4_W(31) AM_P4_W(32) AM_P4_W(33) AM_P4_W(34) AM_P4_W(35) AM_P4_W(36)
-    default: if (k < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;   // (> 36: waiting for more than necessary is safe)
-    }
-#undef AM_P4_W
-}
-
-// one step's place in the packed planes and this group's share of its rows
-struct P4Geo {
-    int nt;            // 16-row tiles of this group at this step (0: nothing to do)
-    int rows_valid;    // live rows from the group's first row on
-    unsigned row;      // packed row of the group's first row:  step_off[t] + slot_base + 16 * first tile
-    unsigned prev;     // the same slots' packed row at step t - 1
-};
-
-__device__ __forceinline__ P4Geo p4_geo(const LstmPersistArgs& a, int t, int n_act, int g, int NG)
-{
-    P4Geo o{0, 0, 0u, 0u};
-    const int tiles = (n_act + 15) >> 4;
-    if (tiles <= 0) return o;
-    const int q = (tiles + NG - 1) / NG;
-    const int tile0 = g * q;
-    int nt = tiles - tile0;
-    if (nt > q) nt = q;
-    if (nt <= 0) return o;
-    o.nt = nt;
-    o.rows_valid = n_act - tile0 * 16;
-    const unsigned slot0 = (unsigned)(a.slot_base + tile0 * 16);
-    o.row = (unsigned)a.step_off[t] + slot0;
-    o.prev = t > 0 ? (unsigned)a.step_off[t - 1] + slot0 : 0u;
-    return o;
-}
-
-// Wave 0: lane j < n keeps an eye on counter first + j.  `issue` starts the load (asynchronous: the value is looked at a batch
-// later), `ready` says whether every counter had reached its target when it was read, `block` spins (bounded) until it has.
-struct P4Poll { unsigned v, target; };
-__device__ __forceinline__ void p4_poll_issue(P4Poll& p, const LstmPersistArgs& a, int first, int n, int tcol, int lane)
-{
-    p.v = 0xffffffffu; p.target = 0u;
-    if (lane < n) {
-        p.target = a.cum[(size_t)(first + lane) * a.T + tcol];
-        p.v = ld_agent_u32(a.counters + first + lane);
-    }
-}
-__device__ __forceinline__ bool p4_poll_ready(const P4Poll& p) { return __ballot(p.v < p.target) == 0ull; }
-__device__ __forceinline__ bool p4_poll_block(P4Poll& p, const LstmPersistArgs& a, int first, int lane)   // false: gave up
-{
-    bool ok = true;
-    if (p.v < p.target) {
-        const unsigned* c = a.counters + first + lane;
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        int it = 0;
-        while ((p.v = ld_agent_u32(c)) < p.target) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++it & 63) == 0 && (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-                                    __builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)LSTM_P_TIMEOUT)) { ok = false; break; }
-        }
-    }
-    return __ballot(!ok) == 0ull;
-}
-
-// the ring's book-keeping, per wave: LDS-DMA instructions issued so far, and that count right after each buffer's current tile
-struct P4Ring { int iss; int mark[4]; };
-
-// One tile = n_inst LDS-DMA instructions per wave (an instruction moves two 512-B rows; n_inst = 2 x row tiles): the rows of the
-// 128-k batch at `src` (wave-uniform: plane + first row + batch) into ring buffer `buf`.  Rows past rows_valid repeat the last valid
-// row (never a row that may not have been written yet); the 16-B chunk index is XOR-ed with the row's low four bits on the source
-// side (conflict-free ds_read_b128, as in the first form).  N_INST > 0: compile-time count (unrolled).
-template <int N_INST>
-__device__ __forceinline__ void p4_issue_tile(const float* src, int rows_valid, int n_inst, float* buf, int U_pad, int wave, int lane)
-{
-    asm volatile("" : "+v"(lane));   // (opaque, as in p4_issue_one)
-    const int drow = lane >> 5, dchunk = lane & 31;
-    auto one = [&](int e) {
-        const int row = 2 * (wave + 4 * e) + drow;
-        const int srow = row < rows_valid ? row : rows_valid - 1;
-        const unsigned off = (unsigned)srow * (unsigned)U_pad + 4u * (unsigned)(dchunk ^ (row & 15));
-        __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(src + off), AM_LDS_PTR(buf + (wave + 4 * e) * 256), 16, 0, 16 /* sc1 */);
-    };
-    if (N_INST > 0) {
-#pragma unroll
-        for (int e = 0; e < N_INST; ++e) one(e);
-    } else {
-        for (int e = 0; e < n_inst; ++e) one(e);
-    }
-}
-
-// A tile whose LDS-DMA instructions are issued BETWEEN the MFMA groups that follow its request (one wave per SIMD: what is issued in
-// front of a batch delays it in full -- 8 instructions cost 0.2 - 0.3 us of a 1.7-us batch): wave-uniform description.
-struct P4Pend { unsigned src; int buf; int rows_valid, n_inst; };   // src: float offset into the plane (upward tiles: Hin, lateral: H; told by the
-                                                                    // position), buf: float offset into the ring -- 32-bit scalars, SGPRs are scarce here too
-
-// Instruction e of a tile: rows 2 (wave + 4 e) and + 1.  The lane's part of the address does not depend on the step: row term
-// (2 wave + drow) U_pad plus the swizzled chunk, whose row bits alternate with e's parity (lane_off[e & 1], computed once per kernel);
-// the 8 e rows go to the scalar base.  Where the pair of rows is not wholly valid (the last, partial tile of a step) rows past the
-// valid ones repeat the last valid row -- never a row that may not have been written yet.
-__device__ __forceinline__ void p4_issue_one(const P4Pend& t, const float* plane, float* ring, int e, int U_pad, int wave, int lane, unsigned lane_off0, unsigned lane_off1)
-{
-    float* dst = ring + t.buf + (wave + 4 * e) * 256;
-    const float* src = plane + t.src;
-    if (2 * (wave + 4 * e) + 1 < t.rows_valid) {
-        __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(src + (size_t)(8 * e) * U_pad + ((e & 1) ? lane_off1 : lane_off0)), AM_LDS_PTR(dst), 16, 0, 16 /* sc1 */);
-    } else {
-        asm volatile("" : "+v"(lane));   // (opaque: nothing of this rare path is worth a register across the time loop)
-        const int drow = lane >> 5, dchunk = lane & 31;
-        const int row = 2 * (wave + 4 * e) + drow;
-        const int srow = row < t.rows_valid ? row : t.rows_valid - 1;
-        const unsigned off = (unsigned)srow * (unsigned)U_pad + 4u * (unsigned)(dchunk ^ (row & 15));
-        __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(src + off), AM_LDS_PTR(dst), 16, 0, 16 /* sc1 */);
-    }
-}
-
-// The MFMAs of one 128-k batch: both K halves (separate chains from zero, folded into the running sums afterwards: the per-step
-// kernels' order), NT row tiles, this wave's 16 gate columns.  Weights are the ROW operand: a lane receives the four gates
-// (registers 0..3) of unit lq for utterance row l15.
-//
-// MFMA with the weight operand read straight from an accumulation register ("a"): the 256 resident weight registers of an upper
-// layer fill the AGPR half of the wave's 512 exactly and never pass through the VGPR half.  Inline asm: the compiler pads no hazards
-// for it -- a chain's first MFMA takes the literal 0 as its C operand (no freshly written VGPR is read), the chain continues on its
-// own result (no wait states needed), and p4_batch ends with the wait states a VALU reader of the last results needs.
-__device__ __forceinline__ void p4_mfma_first(f32x4& d, float w, float x) { asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(d) : "a"(w), "v"(x)); }
-__device__ __forceinline__ void p4_mfma(f32x4& d, float w, float x) { asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(d) : "a"(w), "v"(x)); }
-
-constexpr int P4_MIDG = 5;   // the MFMA group (of 8 per batch) behind which a batch prepares the next one: landing wait, barrier, requests
-
-// One batch.  The asm MFMAs are scheduling barriers for the compiler, so the software pipeline is written out by hand:
-//   * fragments of group g + 1 (a group = one 16-k sub-step of one K half; with NT <= 2 of both halves, see below) are requested in
-//     front of group g's MFMAs; the LAST group requests the first fragments of the NEXT batch (next_off >= 0) -- `af` lives across
-//     batches, and a batch enters with its first fragments under way;
-//   * hook(g): the pending tiles' LDS-DMA instructions, one or two per group, between the group's MFMAs;
-//   * mid(): behind group P4_MIDG -- the next tile's landing wait, the workgroup's barrier and the requests that have come due.  In the
-//     middle of a batch they cost the barrier's skew; at its start they would cost the whole chain (wait, barrier, first fragment
-//     round trip: ~0.35 us of a 2-us batch with nothing to overlap them, one wave per SIMD).
-template <int NT> struct P4Frag { f32x4 v[2][NT <= 2 ? 2 : 1][NT]; };
-
-template <int NT>
-__device__ __forceinline__ void p4_first_fragments(P4Frag<NT>& af, const float* ring, int row_off, int buf_off, const int (&xs)[LSTM_KS])
-{
-    asm volatile("" : "+v"(row_off));
-    const float* sa = ring + row_off + buf_off;
-#pragma unroll
-    for (int h = 0; h < (NT <= 2 ? 2 : 1); ++h)
-#pragma unroll
-        for (int r = 0; r < NT; ++r) af.v[0][h][r] = *(const f32x4*)(sa + r * 16 * PERSIST_TILE_LD + h * (LSTM_KB / 2) + xs[0]);
-}
-
-template <int NT, class Hook, class Mid>
-__device__ __forceinline__ void p4_batch(const float* ring, int row_off /* floats: l15 * 128 */, int buf_off /* this batch's ring buffer */, int next_off /* the next batch's, or < 0 */,
-                                         const int (&xs)[LSTM_KS], const f32x4 (&w)[2][LSTM_KS], f32x4 (&acc)[2][NT], P4Frag<NT>& af, Hook&& hook, Mid&& mid)
-{
-    // One address register per fragment group: the lane's row offset is made opaque here, so the compiler adds the buffer and the sub-step's
-    // chunk offset when they are needed (row tile and K half are immediates) instead of keeping an address register per (ring buffer,
-    // sub-step) alive across the whole time loop -- that, not the arithmetic, is what overflowed the 256 VGPRs beside the 256 weight registers.
-    asm volatile("" : "+v"(row_off));
-    const float* sa = ring + row_off + buf_off;
-    const float* sn = ring + row_off + (next_off >= 0 ? next_off : 0);
-    f32x4 pb[2][NT];
-    if constexpr (NT <= 2) {
-        // Few rows: a group is one 16-k sub-step of BOTH K halves, their MFMAs interleaved -- with one row tile the four MFMAs of a
-        // sub-step would otherwise follow each other on one accumulator, and a dependent 16x16x4 waits 40 cycles where an independent
-        // one issues after 32.
-#pragma unroll
-        for (int s = 0; s < LSTM_KS; ++s) {
-            if (s + 1 < LSTM_KS) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int r = 0; r < NT; ++r) af.v[(s + 1) & 1][h][r] = *(const f32x4*)(sa + r * 16 * PERSIST_TILE_LD + h * (LSTM_KB / 2) + xs[s + 1]);
-            } else if (next_off >= 0) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int r = 0; r < NT; ++r) af.v[0][h][r] = *(const f32x4*)(sn + r * 16 * PERSIST_TILE_LD + h * (LSTM_KB / 2) + xs[0]);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int r = 0; r < NT; ++r) {
-                        if (s == 0 && j == 0) p4_mfma_first(pb[h][r], w[h][s][j], af.v[s & 1][h][r][j]);
-                        else p4_mfma(pb[h][r], w[h][s][j], af.v[s & 1][h][r][j]);
-                    }
-                if (j == 0) hook(2 * s);
-                if (j == 2) hook(2 * s + 1);
-                if (2 * s + (j >> 1) == P4_MIDG && (j & 1) == 1) mid();
-            }
-        }
-    } else {
-#pragma unroll
-        for (int g = 0; g < 2 * LSTM_KS; ++g) {
-            const int s = g >> 1, h = g & 1;
-            if (g + 1 < 2 * LSTM_KS) {
-#pragma unroll
-                for (int r = 0; r < NT; ++r) af.v[(g + 1) & 1][0][r] = *(const f32x4*)(sa + r * 16 * PERSIST_TILE_LD + ((g + 1) & 1) * (LSTM_KB / 2) + xs[(g + 1) >> 1]);
-            } else if (next_off >= 0) {
-#pragma unroll
-                for (int r = 0; r < NT; ++r) af.v[0][0][r] = *(const f32x4*)(sn + r * 16 * PERSIST_TILE_LD + xs[0]);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int r = 0; r < NT; ++r) {
-                    if (s == 0 && j == 0) p4_mfma_first(pb[h][r], w[h][s][j], af.v[g & 1][0][r][j]);
-                    else p4_mfma(pb[h][r], w[h][s][j], af.v[g & 1][0][r][j]);
-                }
-                if (j == 0) hook(g);
-            }
-            if (g == P4_MIDG) mid();
-        }
-    }
-    // wait states between the last MFMAs and the VALU readers of their results (8-pass MFMA: 11; the compiler pads nothing for asm).  The
-    // statement names every partial sum as an operand, so no reader can be scheduled in front of it.
-    if constexpr (NT == 1) asm volatile("s_nop 15" : "+v"(pb[0][0]), "+v"(pb[1][0]));
-    else if constexpr (NT == 2) asm volatile("s_nop 15" : "+v"(pb[0][0]), "+v"(pb[1][0]), "+v"(pb[0][1]), "+v"(pb[1][1]));
-    else if constexpr (NT == 3) asm volatile("s_nop 15" : "+v"(pb[0][0]), "+v"(pb[1][0]), "+v"(pb[0][1]), "+v"(pb[1][1]), "+v"(pb[0][2]), "+v"(pb[1][2]));
-    else if constexpr (NT == 4) asm volatile("s_nop 15" : "+v"(pb[0][0]), "+v"(pb[1][0]), "+v"(pb[0][1]), "+v"(pb[1][1]), "+v"(pb[0][2]), "+v"(pb[1][2]), "+v"(pb[0][3]), "+v"(pb[1][3]));
-    else if constexpr (NT == 5) asm volatile("s_nop 15" : "+v"(pb[0][0]), "+v"(pb[1][0]), "+v"(pb[0][1]), "+v"(pb[1][1]), "+v"(pb[0][2]), "+v"(pb[1][2]), "+v"(pb[0][3]), "+v"(pb[1][3]), "+v"(pb[0][4]), "+v"(pb[1][4]));
-    else asm volatile("s_nop 15" : "+v"(pb[0][0]), "+v"(pb[1][0]), "+v"(pb[0][1]), "+v"(pb[1][1]), "+v"(pb[0][2]), "+v"(pb[1][2]), "+v"(pb[0][3]), "+v"(pb[1][3]), "+v"(pb[0][4]), "+v"(pb[1][4]), "+v"(pb[0][5]), "+v"(pb[1][5]));
-    static_assert(NT <= 6, "p4_batch names its partial sums one by one");
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int r = 0; r < NT; ++r) acc[h][r] += pb[h][r];
-}
-
-// per-workgroup constants of the time loop
-struct P4Ctx {
-    int li, gidx, ut;
-    int wave, lane, l15, lq;
-    int U_pad;
-    unsigned lane_off0, lane_off1;   // p4_issue_one (two named members: an array indexed at run time would put the whole struct in scratch)
-    float* ring;       // tile buffers
-    float* stage;      // h / c on their way out: [2][96][P4_SLD]
-    int* s_flag;       // [0] abort, [1] "the next step's upward tiles may be requested"
-};
-
-// One time step of one workgroup.  UP: layers >= 1 (upward + lateral product); layer 0: lateral only, its upward term is G.
-// ge : this step's geometry; nx: the next step's (nx.nt == 0: none) for the prefetch of its upward tiles
-// pre: the first tiles of this step's upward product were requested during the previous step
-// returns 0 = aborted, 1 = done, 2 = done and the next step's first upward tiles are under way
-//
-// The step's tiles form one stream of positions: upper layers U0..U3 = 0..3, L0..L3 = 4..7 (t > 0), then the NEXT step's U0..U2 =
-// 8..10; layer 0: L0..L3 = 0..3.  Position p lives in ring buffer p % NBUF.  While batch i is multiplied, its mid() makes sure tile
-// i + 1 has landed for everybody (barrier) and requests position i + LOOK -- the buffer of tile i - 1, which everybody has left.
-// Dependencies gate the requests: L0 (position 4, due at mid(1)) needs every group of this layer to have published step t - 1 -- a
-// poll started at the step's entry is looked at there, blocking; the next step's U0 (position 8, due at mid(5)) needs the layer
-// below to have published step t + 1 -- a poll started at mid(3) is looked at at mid(4), NOT blocking: if it has not arrived the step
-// ends without prefetch and the next one starts cold (which makes this layer lag a little more behind the one below: self-adjusting).
-template <int NB, bool UP, int NT>
-__device__ __forceinline__ int p4_step(const LstmPersistArgs& a, const LstmPersistLayer& Ly, const P4Ctx& c, P4Ring& rg, int t, const P4Geo& ge, const P4Geo& nx, bool pre,
-                                        const f32x4 (&wu)[UP ? NB : 1][2][LSTM_KS], const f32x4 (&wl)[NB][2][LSTM_KS], const f32x4& biasq)
-{
-    static_assert(NB == 4, "the tile schedule below is written for 512-unit stacks (four 128-k batches per product)");
-    constexpr int NBUF = UP ? 4 : 3;
-    constexpr int BUF_FLOATS = (UP ? 64 : 96) * PERSIST_TILE_LD;
-    constexpr int NI = 2 * NT;                        // LDS-DMA instructions per wave and tile of THIS step
-    constexpr int LOOK = NBUF - 1;                    // tiles under way ahead of the one being multiplied
-    constexpr int P_L0 = UP ? NB : 0;                 // stream position of the first lateral tile
-    const int U_pad = c.U_pad, wave = c.wave, lane = c.lane, l15 = c.l15, lq = c.lq, tid = threadIdx.x;
-    const bool lat = t > 0;
-    const unsigned r_t = ge.row, r_p = ge.prev;
-    const int rows_valid = ge.rows_valid;
-    persist_stamp(a, c.gidx, c.ut, t, 0);
-
-    int xs[LSTM_KS];                                  // fragment of sub-step s: chunk (4 s + lq) ^ l15 of the row's K half (the second half: + 64 floats, an immediate)
-#pragma unroll
-    for (int s = 0; s < LSTM_KS; ++s) xs[s] = 4 * (((4 * s + lq) ^ l15) & 15);
-    const int row_off = l15 * PERSIST_TILE_LD;
-    f32x4 acc[2][NT];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int r = 0; r < NT; ++r) acc[h][r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    P4Frag<NT> af;
-
-    const int nni = 2 * nx.nt;
-    // position -> tile: upward tiles read the plane of the layer below (this step's rows; positions past 2 NB: the next step's), lateral
-    // tiles this layer's own plane (the previous step's rows)
-    auto is_lat = [&](int pos) { return UP ? (pos >= NB && pos < 2 * NB) : true; };
-    auto tile_of = [&](int pos) {
-        P4Pend t_;
-        t_.buf = (pos % NBUF) * BUF_FLOATS;
-        if (UP && pos < NB) { t_.src = r_t * (unsigned)U_pad + pos * LSTM_KB; t_.rows_valid = rows_valid; t_.n_inst = NI; }
-        else if (pos < P_L0 + NB) { t_.src = r_p * (unsigned)U_pad + (pos - P_L0) * LSTM_KB; t_.rows_valid = rows_valid; t_.n_inst = NI; }
-        else { t_.src = nx.row * (unsigned)U_pad + (pos - 2 * NB) * LSTM_KB; t_.rows_valid = nx.rows_valid; t_.n_inst = nni; }
-        return t_;
-    };
-    auto book = [&](int pos, int n) { rg.iss += n; rg.mark[pos % NBUF] = rg.iss; };
-    // request now (cold starts, and behind the publish) ...
-    auto request = [&](int pos) {
-        const P4Pend t_ = tile_of(pos);
-        for (int e = 0; e < t_.n_inst; ++e) p4_issue_one(t_, is_lat(pos) ? Ly.H : Ly.Hin, c.ring, e, U_pad, wave, lane, c.lane_off0, c.lane_off1);
-        book(pos, t_.n_inst);
-    };
-    // ... or spread over the eight MFMA groups that follow the mid() it came due in: instructions k and k + 8 in the k-th of them.  A tile
-    // requested at one batch's mid is fully issued before the next batch's (the count in `rg` is right at every landing wait).
-    P4Pend pendA{0u, 0, 0, 0}, pendB{0u, 0, 0, 0};     // came due at the previous / at this batch's mid (n_inst == 0: none)
-    bool latA = false, latB = false;                   // ... and which plane they read
-    auto defer = [&](int pos) { pendB = tile_of(pos); latB = is_lat(pos); book(pos, pendB.n_inst); };
-    auto hook = [&](int g) {
-        if (g <= P4_MIDG) {
-            const int k = g + (7 - P4_MIDG);
-            if (k < pendA.n_inst) p4_issue_one(pendA, latA ? Ly.H : Ly.Hin, c.ring, k, U_pad, wave, lane, c.lane_off0, c.lane_off1);
-            if (k + 8 < pendA.n_inst) p4_issue_one(pendA, latA ? Ly.H : Ly.Hin, c.ring, k + 8, U_pad, wave, lane, c.lane_off0, c.lane_off1);
-        } else {
-            const int k = g - (P4_MIDG + 1);
-            if (k < pendB.n_inst) p4_issue_one(pendB, latB ? Ly.H : Ly.Hin, c.ring, k, U_pad, wave, lane, c.lane_off0, c.lane_off1);
-            if (k + 8 < pendB.n_inst) p4_issue_one(pendB, latB ? Ly.H : Ly.Hin, c.ring, k + 8, U_pad, wave, lane, c.lane_off0, c.lane_off1);
-        }
-    };
-    auto next_batch = [&] { pendA = pendB; latA = latB; pendB.n_inst = 0; };
-    auto landed = [&](int pos) { p4_wait_vmcnt_dyn(rg.iss - rg.mark[pos % NBUF]); };
-    auto barrier = [&] { __builtin_amdgcn_s_barrier(); };
-    // (a flag written in front of a raw s_barrier: the LDS store must have completed before the wave arrives -- lgkmcnt(0))
-    auto give_up = [&] { __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *(volatile int*)c.s_flag = 1; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
-    auto aborted = [&] { return __builtin_amdgcn_readfirstlane(*(volatile int*)c.s_flag) != 0; };   // (readfirstlane: one value, a uniform branch)
-    auto off_of = [&](int pos) { return (pos % NBUF) * BUF_FLOATS; };   // float offset of a position's ring buffer
-
-    P4Poll poll{0xffffffffu, 0u};
-    int next = 0;                                      // 1: the next step's upward tiles are requested during this step
-    bool dead = false;
-    const int first_l = a.L[UP ? c.li - 1 : 0].group0, n_l = a.L[UP ? c.li - 1 : 0].n_groups;   // the layer below (upper layers)
-
-    // previous cell state and (layer 0) the four gates' upward terms of (row l15 of tile r, unit lq)
-    f32x4 gq[NT];
-    float cq[NT];
-#pragma unroll
-    for (int r = 0; r < NT; ++r) { cq[r] = 0.0f; gq[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
-    const int uq = 4 * wave + lq;                      // this lane's unit inside the workgroup's 16
-    auto fetch_epilogue = [&] {
-        const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.Cst, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-        for (int r = 0; r < NT; ++r) {
-            const int row = r * 16 + l15;
-            if (row < rows_valid) {
-                if (!UP) gq[r] = *(const f32x4*)(Ly.G + (size_t)(r_t + row) * (size_t)(4 * U_pad) + c.ut * 64 + 4 * uq);
-                if (lat) cq[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(crs, (int)(((r_p + row) * (unsigned)U_pad + (unsigned)(c.ut * 16 + uq)) * 4u), 0, 16 /* sc1 */));
-            }
-        }
-    };
-
-    // ---------------- entry ----------------
-    if (UP || lat) {
-        if (!UP || !pre) {   // cold: wait for the layer below (upper layers) / for this layer's previous step (layer 0), then request the first tiles
-            if (wave == 0) {
-                if (UP) { p4_poll_issue(poll, a, first_l, n_l, t, lane); if (!p4_poll_block(poll, a, first_l, lane)) give_up(); }
-                else { p4_poll_issue(poll, a, Ly.group0, Ly.n_groups, t - 1, lane); if (!p4_poll_block(poll, a, Ly.group0, lane)) give_up(); }
-            }
-            __syncthreads();
-            if (aborted()) return 0;
-#pragma unroll
-            for (int p = 0; p < LOOK; ++p) request(p);
-            landed(0);
-            barrier();
-        }
-        persist_stamp(a, c.gidx, c.ut, t, 1);
-        // upper layers: the lateral dependency (every group of THIS layer has published step t - 1) -- asked for now, looked at in mid(1)
-        if (UP && lat && wave == 0) p4_poll_issue(poll, a, Ly.group0, Ly.n_groups, t - 1, lane);
-        p4_first_fragments<NT>(af, c.ring, row_off, off_of(0), xs);
-    }
-    // ---------------- the batches ----------------
-    if (UP) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const bool more = b + 1 < NB || lat;       // another tile of this step follows
-            p4_batch<NT>(c.ring, row_off, off_of(b), more ? off_of(b + 1) : -1, xs, wu[UP ? b : 0], acc, af, hook, [&] {
-                if (dead || !more) return;
-                landed(b + 1);
-                if (lat && b == 1 && wave == 0) { if (!p4_poll_block(poll, a, Ly.group0, lane)) give_up(); }   // L0 comes due here
-                barrier();
-                if (lat && b == 1 && aborted()) { dead = true; return; }
-                if (b + LOOK < NB) defer(b + LOOK);
-                else if (lat) defer(b + LOOK);        // lateral tiles 0 .. 2 at the mids of U1 .. U3
-                if (lat && b == NB - 1 && nx.nt > 0 && wave == 0) p4_poll_issue(poll, a, first_l, n_l, t + 1, lane);   // looked at in mid(L0)
-            });
-            next_batch();
-            if (dead) return 0;
-        }
-        persist_stamp(a, c.gidx, c.ut, t, 2);
-    }
-    if (lat) {
-        if (!UP) fetch_epilogue();                     // layer 0: G and c rows ride beside the first batch
-        persist_stamp(a, c.gidx, c.ut, t, 3);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int pos = P_L0 + b;
-            p4_batch<NT>(c.ring, row_off, off_of(pos), b + 1 < NB ? off_of(pos + 1) : -1, xs, wl[b], acc, af, hook, [&] {
-                if (b + 1 >= NB) return;
-                landed(pos + 1);
-                if (UP && b == 0 && nx.nt > 0 && wave == 0) {   // (asked for a batch ago)
-                    *(volatile int*)(c.s_flag + 1) = p4_poll_ready(poll) ? 1 : 0;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                barrier();
-                if (UP && b == 0 && nx.nt > 0) next = __builtin_amdgcn_readfirstlane(*(volatile int*)(c.s_flag + 1));
-                if (b + LOOK < NB) defer(pos + LOOK);                       // the rest of this product
-                else if (UP && next && b + LOOK < NB + LOOK - 1) defer(pos + LOOK);   // the next step's U0, U1 (U2: behind the publish)
-                if (UP && b == 0) fetch_epilogue();    // (the hand-off of step t - 1 has arrived: its c rows may be read)
-            });
-            next_batch();
-        }
-    } else fetch_epilogue();
-    persist_stamp(a, c.gidx, c.ut, t, 4);
-    // ---------------- gates: in registers ----------------
-    float* sH = c.stage;
-    float* sC = c.stage + 96 * P4_SLD;
-#pragma unroll
-    for (int r = 0; r < NT; ++r) {
-        const int row = r * 16 + l15;
-        const f32x4 pre4 = (acc[0][r] + acc[1][r]) + (UP ? biasq : gq[r]);
-        const float ga = am_tanh_rec(pre4[0]);
-        const float gi = am_sigmoid_rec(pre4[1]);
-        const float gf = am_sigmoid_rec(pre4[2]);
-        const float go = am_sigmoid_rec(pre4[3]);
-        const float ai = ga * gi;
-        const float fc = gf * cq[r];
-        const float cn = ai + fc;
-        sC[row * P4_SLD + uq] = cn;
-        sH[row * P4_SLD + uq] = go * am_tanh_rec(cn);
-    }
-    __syncthreads();
-    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.Cst, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.H, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < (NT * 64 + P4_THREADS - 1) / P4_THREADS; ++i) {
-        const int idx = tid + P4_THREADS * i, row = idx >> 2, quad = idx & 3;
-        if (row < NT * 16 && row < rows_valid) {
-            const f32x4 hn = *(const f32x4*)(sH + row * P4_SLD + 4 * quad);
-            const f32x4 cn = *(const f32x4*)(sC + row * P4_SLD + 4 * quad);
-            const unsigned off = ((r_t + row) * (unsigned)U_pad + (unsigned)(c.ut * 16 + 4 * quad)) * 4u;
-            st_sc1_b128(crs, off, cn);
-            st_sc1_b128(hrs, off, hn);
-        }
-    }
-    persist_stamp(a, c.gidx, c.ut, t, 5);
-    // publish: every storing wave drains its stores (and with them the prefetched tiles: they are older), the workgroup meets, ONE lane signals
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(a.counters + c.gidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (UP && next) request(2 * NB + LOOK - 1);        // the last tile of the lookahead, behind the publish
-    persist_stamp(a, c.gidx, c.ut, t, 6);
-    return next ? 2 : 1;
-}
-
-template <int NB, bool UP>
-__device__ __forceinline__ void p4_body(const LstmPersistArgs& a, const LstmPersistLayer& Ly, int li, int gidx, int ut, float* smem, int* s_flag)
-{
-    constexpr int NTMAX = UP ? 4 : 6;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, lq = lane >> 4;
-    const int U_pad = a.U_pad;
-    const int g = gidx - Ly.group0, NG = Ly.n_groups;
-    P4Ctx c;
-    c.li = li; c.gidx = gidx; c.ut = ut; c.wave = wave; c.lane = lane; c.l15 = l15; c.lq = lq; c.U_pad = U_pad;
-    c.ring = smem;
-    // staging area of the outgoing h / c rows: behind the ring (upper layers); layer 0's ring fills the whole allocation, its buffer 2 is
-    // idle from the last batch of a step to the first request of the next one
-    c.stage = UP ? smem + P4_RING_UP / sizeof(float) : smem + 2 * 96 * PERSIST_TILE_LD;
-    c.s_flag = s_flag;
-    {
-        const int drow = lane >> 5, dchunk = lane & 31;
-        c.lane_off0 = (unsigned)(2 * wave + drow) * (unsigned)U_pad + 4u * (unsigned)(dchunk ^ ((2 * wave + drow) & 15));
-        c.lane_off1 = (unsigned)(2 * wave + drow) * (unsigned)U_pad + 4u * (unsigned)(dchunk ^ ((2 * wave + drow + 8) & 15));
-    }
-    // the resident weights: column i = l15 of this wave is gate (l15 & 3) of unit 4 wave + (l15 >> 2) -- gate-tiled row 64 ut + 16 gate + unit;
-    // per 128-k batch both K halves, 4 consecutive k per lane and sub-step (the K permutation of every recurrent kernel here)
-    f32x4 wl[NB][2][LSTM_KS], wu[UP ? NB : 1][2][LSTM_KS];
-    {
-        const size_t wrow = (size_t)(ut * 64 + (l15 & 3) * 16 + 4 * wave + (l15 >> 2)) * U_pad + 4 * lq;
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int s = 0; s < LSTM_KS; ++s) {
-                    wl[b][h][s] = *(const f32x4*)(Ly.Wlat + wrow + b * LSTM_KB + h * (LSTM_KB / 2) + 16 * s);
-                    if (UP) wu[b][h][s] = *(const f32x4*)(Ly.Wup + wrow + b * LSTM_KB + h * (LSTM_KB / 2) + 16 * s);
-                }
-    }
-    f32x4 biasq = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};     // upper layers: the four gates' biases of this lane's unit
-    if (UP) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) biasq[k] = Ly.bias[ut * 64 + k * 16 + 4 * wave + lq];
-    }
-    auto local_rows = [&](int n) { n -= a.slot_base; return n < 0 ? 0 : (n > a.slot_cap ? a.slot_cap : n); };   // this launch's share of the active slots
-    P4Ring rg{0, {0, 0, 0, 0}};
-    const int t0 = a.t_begin, t1 = a.t_end > 0 ? a.t_end : a.T;   // this launch's steps; nothing is prefetched for a step it does not run
-    int n_cur = local_rows(a.n_active[t0]);
-    P4Geo cur = p4_geo(a, t0, n_cur, g, NG);
-    int n_nxt = t0 + 1 < t1 ? local_rows(a.n_active[t0 + 1]) : 0;
-    P4Geo nxt = t0 + 1 < t1 ? p4_geo(a, t0 + 1, n_nxt, g, NG) : P4Geo{0, 0, 0u, 0u};
-    bool pre = false;
-    for (int t = t0; t < t1; ++t) {
-        const int n_nn = t + 2 < t1 ? local_rows(a.n_active[t + 2]) : 0;      // a step ahead: the scalar loads' latency is off the chain
-        const P4Geo nn = t + 2 < t1 ? p4_geo(a, t + 2, n_nn, g, NG) : P4Geo{0, 0, 0u, 0u};
-        if (n_cur <= 0) break;
-        if (cur.nt > 0) {                              // (0: nothing for this group at this step -- the host's arrival table knows)
-            int ret = 1;
-            switch (cur.nt) {
-            case 1: ret = p4_step<NB, UP, 1>(a, Ly, c, rg, t, cur, nxt, pre, wu, wl, biasq); break;
-            case 2: ret = p4_step<NB, UP, 2>(a, Ly, c, rg, t, cur, nxt, pre, wu, wl, biasq); break;
-            case 3: ret = p4_step<NB, UP, 3>(a, Ly, c, rg, t, cur, nxt, pre, wu, wl, biasq); break;
-            case 4: ret = p4_step<NB, UP, 4>(a, Ly, c, rg, t, cur, nxt, pre, wu, wl, biasq); break;
-            case 5: if (NTMAX >= 5) ret = p4_step<NB, UP, NTMAX >= 5 ? 5 : 1>(a, Ly, c, rg, t, cur, nxt, pre, wu, wl, biasq); break;
-            case 6: if (NTMAX >= 6) ret = p4_step<NB, UP, NTMAX >= 6 ? 6 : 1>(a, Ly, c, rg, t, cur, nxt, pre, wu, wl, biasq); break;
-            default: break;
-            }
-            if (ret == 0) return;
-            pre = ret == 2;
-        } else pre = false;
-        n_cur = n_nxt; cur = nxt;
-        n_nxt = n_nn; nxt = nn;
-    }
-}
-
-template <int NB>
-__global__ __launch_bounds__(P4_THREADS, 1) void lstm_persist4_kernel(const LstmPersistArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) float p4_smem[];
-    __shared__ int s_flag[2];
-    if (threadIdx.x == 0) { s_flag[0] = 0; s_flag[1] = 0; }
-    __syncthreads();
-    const int gidx = blockIdx.x % a.n_groups_total, ut = blockIdx.x / a.n_groups_total;
-    int li = 0;
-#pragma unroll
-    for (int l = 1; l < LSTM_MAX_LAYERS; ++l) if (l < a.n_layers && gidx >= a.L[l].group0) li = l;
-    const LstmPersistLayer& Ly = a.L[li];
-    if (li > 0) p4_body<NB, true>(a, Ly, li, gidx, ut, p4_smem, s_flag);
-    else p4_body<NB, false>(a, Ly, li, gidx, ut, p4_smem, s_flag);
-}
 
 // The persistent kernel needs all its workgroups resident at once.  A build of it that spills even one register needs scratch
 // memory, and the FIRST launch of a scratch-using kernel in a process does not get them all resident (measured with a
 // 2-VGPR spill: the first pass of every process ran into the 2-s bound and fell back; later launches were fine).  So the
 // form is only offered when the compiled kernel has no private segment -- a toolchain that starts spilling loses speed, not
 // two seconds per process.
-static const void* lstm_persist_fn(int U_pad, int form)
+static bool lstm_persist_scratch_free(int U_pad)
 {
-    if (form == 2) return U_pad == 512 ? (const void*)lstm_persist4_kernel<4> : nullptr;   // (256-unit stacks: the first form)
-    return U_pad == 512 ? (const void*)lstm_persist_kernel<4> : (const void*)lstm_persist_kernel<2>;
-}
-
-static bool lstm_persist_scratch_free(int U_pad, int form)
-{
-    static int state[2][2] = {{-1, -1}, {-1, -1}};
-    int& st = state[form == 2 ? 1 : 0][U_pad == 512 ? 0 : 1];
+    static int state[2] = {-1, -1};
+    int& st = state[U_pad == 512 ? 0 : 1];
     if (st < 0) {
         hipFuncAttributes at{};
-        const void* fn = lstm_persist_fn(U_pad, form);
-        const hipError_t e = fn ? hipFuncGetAttributes(&at, fn) : hipErrorInvalidValue;
-        if (!fn) { st = 0; return false; }
-        st = (e == hipSuccess && (at.localSizeBytes == 0 || getenv("AM_PERSIST_ALLOW_SCRATCH"))) ? 1 : 0;   // (the override: timeline experiments only)
+        const hipError_t e = U_pad == 512 ? hipFuncGetAttributes(&at, (const void*)lstm_persist_kernel<4>) : hipFuncGetAttributes(&at, (const void*)lstm_persist_kernel<2>);
+        st = (e == hipSuccess && at.localSizeBytes == 0) ? 1 : 0;
         if (!st) fprintf(stderr, "libamfwd: the persistent recurrent kernel of this build uses scratch memory (%zu B per lane); staying on the per-step kernels\n", (size_t)at.localSizeBytes);
     }
     return st == 1;
@@ -2450,21 +1872,20 @@ static bool lstm_persist_scratch_free(int U_pad, int form)
 
 // Workgroups of lstm_persist_kernel the device holds at once: the occupancy the runtime reports for this kernel with its
 // dynamic LDS (147 KB: one per CU) x the CUs the device really has (a partitioned or harvested part has fewer than 256).
-int lstm_persist_resident_wgs(int U_pad, int n_cus, int form)
+int lstm_persist_resident_wgs(int U_pad, int n_cus)
 {
     if (U_pad != 256 && U_pad != 512) return 0;
     int per_cu = 0;
-    if (!lstm_persist_fn(U_pad, form)) return 0;
-    const hipError_t e = form == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_fn(U_pad, 2), P4_THREADS, P4_LDS)
-                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_fn(U_pad, 1), 512, LSTM_PERSIST_LDS);
+    const hipError_t e = U_pad == 512 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)lstm_persist_kernel<4>, 512, LSTM_PERSIST_LDS)
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)lstm_persist_kernel<2>, 512, LSTM_PERSIST_LDS);
     if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
     return per_cu > 0 ? n_cus : 0;   // the groups are laid out one workgroup per CU even where two would fit
 }
 
-int lstm_persist_capacity(int U_pad, int n_layers, int max_wgs, int form)
+int lstm_persist_capacity(int U_pad, int n_layers, int max_wgs)
 {
     if ((U_pad != 256 && U_pad != 512) || n_layers < 1 || n_layers > LSTM_MAX_LAYERS) return 0;
-    if (!lstm_persist_scratch_free(U_pad, form)) return 0;
+    if (!lstm_persist_scratch_free(U_pad)) return 0;
     const int nb = U_pad / LSTM_KB, budget = max_wgs / (U_pad / 16);
     int tiles = 0;
     for (int t0 = 1; t0 <= 4096; ++t0) {
@@ -2523,57 +1944,21 @@ bool plan_lstm_persist(LstmPersistArgs& a, int n_slots, const int* n_active, uns
 
 size_t lstm_persist_cum_size(const LstmPersistArgs& a) { return (size_t)a.n_groups_total * a.T; }
 
-// One wave that returns once the `n` groups first.. have reached their step-`tcol` arrival targets (bounded like every other wait).
-// Launched on a second stream in front of the output layer's GEMM for the rows of steps <= tcol: as the persistent kernel's
-// workgroups run out of rows and leave, that GEMM takes over their CUs while the few remaining utterances are still stepping.
-__global__ __launch_bounds__(64) void lstm_gate_kernel(const unsigned* counters, const unsigned* cum, int T, int first, int n, int tcol, int* abort_flag, unsigned long long timeout)
-{
-    const int lane = threadIdx.x;
-    if (lane >= n) return;
-    const unsigned target = cum[(size_t)(first + lane) * T + tcol];
-    const unsigned* c = counters + first + lane;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    int it = 0;
-    while (ld_agent_u32(c) < target) {
-        __builtin_amdgcn_s_sleep(8);
-        if ((++it & 63) == 0 && (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-                                __builtin_amdgcn_s_memrealtime() - t0 > timeout)) {
-            __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-    }
-}
-
-hipError_t launch_lstm_gate(hipStream_t s, const LstmPersistArgs& a, int layer, int tcol)
-{
-    if (layer < 0 || layer >= a.n_layers || tcol < 0 || tcol >= a.T) return hipErrorInvalidValue;
-    // unlike the in-kernel waits (one step's worth of somebody else's work) this one legitimately lasts most of the pass: 2 s + 100 us per step
-    const unsigned long long timeout = (unsigned long long)LSTM_P_TIMEOUT + (unsigned long long)a.T * 10000ull;
-    hipLaunchKernelGGL(lstm_gate_kernel, dim3(1), dim3(64), 0, s, a.counters, a.cum, a.T, a.L[layer].group0, a.L[layer].n_groups, tcol, a.abort_flag, timeout);
-    return hipGetLastError();
-}
-
-hipError_t launch_lstm_persist(hipStream_t s, const LstmPersistArgs& a, int form)
+hipError_t launch_lstm_persist(hipStream_t s, const LstmPersistArgs& a)
 {
     const int grid = a.n_groups_total * (a.U_pad / 16);
     if (grid <= 0 || grid > a.max_wgs) return hipErrorInvalidValue;   // every workgroup must be resident: never more than the device holds
-    if (a.U_pad != 512 && a.U_pad != 256) return hipErrorInvalidValue;
     if (a.t_begin < 0 || a.t_begin >= a.T || a.t_end < 0 || a.t_end > a.T || (a.t_end > 0 && a.t_end <= a.t_begin)) return hipErrorInvalidValue;
-    if (form != 2 && (a.t_begin != 0 || (a.t_end != 0 && a.t_end != a.T))) return hipErrorInvalidValue;   // only the second form runs a part of the time axis
-    if (form == 2) {   // 4 waves x 512 registers (lstm_persist4_kernel)
-        if (a.U_pad != 512) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(lstm_persist4_kernel<4>, dim3(grid), dim3(P4_THREADS), P4_LDS, s, a);
-    } else if (a.U_pad == 512) hipLaunchKernelGGL(lstm_persist_kernel<4>, dim3(grid), dim3(512), LSTM_PERSIST_LDS, s, a);
-    else hipLaunchKernelGGL(lstm_persist_kernel<2>, dim3(grid), dim3(512), LSTM_PERSIST_LDS, s, a);
+    if (a.U_pad == 512) hipLaunchKernelGGL(lstm_persist_kernel<4>, dim3(grid), dim3(512), LSTM_PERSIST_LDS, s, a);
+    else if (a.U_pad == 256) hipLaunchKernelGGL(lstm_persist_kernel<2>, dim3(grid), dim3(512), LSTM_PERSIST_LDS, s, a);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 int lstm_persist_mode()
 {
-    // 0: the per-step kernels; 1: the first persistent form (8 waves x 256 registers); 2: the second (4 x 512, lstm_persist4_kernel).
-    // Read at every upload (A/B measurements, cross-form parity tests).
-    const char* v = getenv("AM_LSTM_PERSIST");
-    return v ? atoi(v) : 2;
+    const char* v = getenv("AM_LSTM_PERSIST");   // 0 keeps the per-step kernels (A/B measurements, cross-form parity tests); read at every upload
+    return v ? atoi(v) : 1;
 }
 
 constexpr size_t LSTM_THIN_LDS_MAX = 72 * 1024;   // two blocks per CU stay co-resident
@@ -2591,8 +1976,6 @@ hipError_t init_lstm_kernels()
     we = hipFuncSetAttribute((const void*)lstm_persist_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_PERSIST_LDS);
     if (we != hipSuccess) return we;
     we = hipFuncSetAttribute((const void*)lstm_persist_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_PERSIST_LDS);
-    if (we != hipSuccess) return we;
-    we = hipFuncSetAttribute((const void*)lstm_persist4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P4_LDS);
     if (we != hipSuccess) return we;
 
     we = hipFuncSetAttribute((const void*)lstm_wreg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_WREG_PAIR_LDS);
