@@ -145,6 +145,10 @@ struct am_pipeline {
     DevBuf d_x, d_ivec, d_in, d_in_s, d_act0, d_act1, d_acc, d_acc2, d_out;
     // the Linear stack as one work-queue launch (gemm_stack_kernel): one activation plane per hidden layer + its counters
     DevBuf d_stack, d_ffsync;          // float [planes][stack_rows * stack_width]; unsigned {abort flag, 8 queues, done[hidden][row tiles]}
+    // Ensembles: two members in flight (alternating streams), so that one member's stack launch fills the CUs the previous one's ragged end
+    // leaves idle: a second set of planes / counters, and one logit buffer per member (combined in member order by finish_kernel).
+    DevBuf d_stack2, d_ffsync2, d_accs;
+    int64_t accs_members = 0;          // member buffers d_accs holds (0: the members run one after the other into d_acc)
     int64_t stack_rows = 0; int stack_width = 0, stack_planes = 0;
     bool used_stack = false;           // the current results came from gemm_stack_kernel (its abort flag is checked before they are handed out)
     bool stack_off = false;            // a stack launch gave up on a wait: this pipeline stays on the per-layer launches
@@ -766,7 +770,7 @@ extern "C" int am_pipeline_destroy(am_pipeline* p)
     for (auto ev : p->ev_chain) if (ev) (void)hipEventDestroy(ev);
     p->drop_graph();
     for (DevBuf* d : {&p->d_shifts, &p->d_add, &p->d_scale, &p->d_rplw, &p->d_rplb, &p->d_rpllb, &p->d_prior, &p->d_x, &p->d_ivec, &p->d_in, &p->d_in_s,
-                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_stack, &p->d_ffsync, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c, &p->d_cplane, &p->d_nact, &p->d_stepoff, &p->d_sync, &p->d_stamps})
+                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_stack, &p->d_ffsync, &p->d_stack2, &p->d_ffsync2, &p->d_accs, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c, &p->d_cplane, &p->d_nact, &p->d_stepoff, &p->d_sync, &p->d_stamps})
         d->release();
     for (auto& pl : p->persist) pl.release();
     am_engine* e = p->e;
@@ -1068,6 +1072,17 @@ extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, i
         if (p->d_stack.ensure(sizeof(float) * (size_t)planes * rows * width) == AM_OK &&
             p->d_ffsync.ensure(sizeof(unsigned) * (FF_SYNC_DONE + (size_t)planes * (rows / GEMM_BM))) == AM_OK) {
             p->stack_rows = rows; p->stack_width = width; p->stack_planes = planes;
+            // ensembles: the second plane set and the per-member logit buffers (4.5 GB for ten 1909-class members at the core-test size);
+            // where that does not fit -- or is over 48 GB -- the members simply run one after the other
+            p->accs_members = 0;
+            const size_t nm = p->members.size(), acc_w0 = (size_t)std::max<int>(m0->C_pad, (int)round_up(m0->C, 256));
+            static const int64_t overlap_on = env_int("AM_FF_MEMBER_OVERLAP", 1);
+            if (nm > 1 && overlap_on && nm * rows * acc_w0 * sizeof(float) <= ((size_t)48 << 30)) {
+                if (p->d_stack2.ensure(sizeof(float) * (size_t)planes * rows * width) == AM_OK &&
+                    p->d_ffsync2.ensure(sizeof(unsigned) * (FF_SYNC_DONE + (size_t)planes * (rows / GEMM_BM))) == AM_OK &&
+                    p->d_accs.ensure(sizeof(float) * nm * rows * acc_w0) == AM_OK) p->accs_members = (int64_t)nm;
+                else { (void)hipGetLastError(); p->d_stack2.release(); p->d_accs.release(); }
+            }
         } else {   // (3 to 13 GB per pipeline at the bench sizes) no room for the planes: the per-layer launches need none
             (void)hipGetLastError();
             p->d_stack.release();
@@ -1086,10 +1101,12 @@ extern "C" int am_ff_upload(am_pipeline* p, const float* x, const float* ivec, i
     return AM_OK;
 }
 
-static int ff_member_forward_stack(am_pipeline* p, int mi, int64_t rows_pad, float* acc)
+static int ff_member_forward_stack(am_pipeline* p, int mi, int64_t rows_pad, float* acc, int set = 0, hipStream_t on = nullptr, int epi_override = -1)
 {
+    // set 1 / `on` / epi_override: the overlapped form of an ensemble (its own planes and counters, the other stream, plain logits out)
     am_engine* e = p->e;
     am_model* m = p->members[mi];
+    hipStream_t st = on ? on : e->stream;
     GemmStackArgs a{};
     const int tiles_m = (int)(rows_pad / GEMM_BM);
     const size_t plane = (size_t)p->stack_rows * p->stack_width;
@@ -1099,7 +1116,7 @@ static int ff_member_forward_stack(am_pipeline* p, int mi, int64_t rows_pad, flo
         GemmStackLayer& S = a.L[l];
         S.W = Ly.W.as<float>(); S.bias = Ly.b.as<float>(); S.ldw = Ly.in_pad;
         if (l < m->n_layers) {
-            S.C = p->d_stack.as<float>() + (size_t)l * plane; S.ldc = Ly.out_pad; S.tiles_n = Ly.out_pad / 256; S.nk = Ly.in_pad / 32;
+            S.C = (set ? p->d_stack2 : p->d_stack).as<float>() + (size_t)l * plane; S.ldc = Ly.out_pad; S.tiles_n = Ly.out_pad / 256; S.nk = Ly.in_pad / 32;
         } else {
             const bool wide = Ly.out_pad % 256 != 0;
             S.C = acc; S.ldc = m->C_pad; S.tiles_n = Ly.out_pad / (wide ? 192 : 256); S.nk = Ly.in_pad / 32;
@@ -1110,17 +1127,18 @@ static int ff_member_forward_stack(am_pipeline* p, int mi, int64_t rows_pad, flo
     a.A0 = p->d_in.as<float>(); a.lda0 = m->in_pad;
     a.n_hidden = m->n_layers; a.tiles_m = tiles_m; a.act = m->act;
     a.out_epi = epilogue_mode(p, mi, &a.out_alpha);
-    unsigned* sync = p->d_ffsync.as<unsigned>();
+    if (epi_override >= 0) { a.out_epi = epi_override; a.out_alpha = 1.f; }
+    unsigned* sync = (set ? p->d_ffsync2 : p->d_ffsync).as<unsigned>();
     a.abort_flag = (int*)sync; a.queues = (int*)sync + FF_SYNC_QUEUES; a.done = sync + FF_SYNC_DONE; a.cum_total = item;
     a.test_extra = env_int("AM_FF_TEST_TIMEOUT", 0) ? 1 : 0;
     if (env_int("AM_FF_STAMPS", 0)) {   // diagnostic timeline of this launch (am_ff_stack_stamps)
         AM_TRY(p->d_stamps.ensure(sizeof(unsigned long long) * 16 * 256));
-        HIP_TRY(hipMemsetAsync(p->d_stamps.p, 0, sizeof(unsigned long long) * 16 * 256, e->stream));
+        HIP_TRY(hipMemsetAsync(p->d_stamps.p, 0, sizeof(unsigned long long) * 16 * 256, st));
         a.stamps = p->d_stamps.as<unsigned long long>();
     }   // test hook: arrival targets nobody reaches -> the waits must time out
-    HIP_TRY(hipMemsetAsync(sync + FF_SYNC_QUEUES, 0, sizeof(unsigned) * (FF_SYNC_DONE - FF_SYNC_QUEUES + (size_t)m->n_layers * tiles_m), e->stream));
+    HIP_TRY(hipMemsetAsync(sync + FF_SYNC_QUEUES, 0, sizeof(unsigned) * (FF_SYNC_DONE - FF_SYNC_QUEUES + (size_t)m->n_layers * tiles_m), st));
     const int out_pad = m->L[m->n_layers].out_pad;
-    AM_TRY(run_kernel(e, K_GEMM_STACK, [&] { return launch_gemm_stack(e->stream, a, out_pad, e->n_cus); }));
+    AM_TRY(run_kernel(e, K_GEMM_STACK, [&] { return launch_gemm_stack(st, a, out_pad, e->n_cus); }, st));
     p->used_stack = true;
     return AM_OK;
 }
@@ -1238,6 +1256,8 @@ static int ff_run_chunks(am_pipeline* p, int64_t chunk_rows, float* host_y)
     bool stack_ok = !split && !p->stack_off && p->stack_planes > 0 && ff_stack_mode() > 0;
     for (auto* m : p->members) stack_ok = stack_ok && ff_stack_shape_ok(m) && m->n_layers <= p->stack_planes && m->max_width <= p->stack_width;
     if (stack_ok) HIP_TRY(hipMemsetAsync(p->d_ffsync.p, 0, sizeof(unsigned), e->stream));   // the abort flag: once per pass
+    const bool overlap_members = stack_ok && p->members.size() > 1 && p->accs_members == (int64_t)p->members.size() && !host_y;
+    if (stack_ok && p->d_ffsync2.p) HIP_TRY(hipMemsetAsync(p->d_ffsync2.p, 0, sizeof(unsigned), e->stream));   // (the second set's flag is read by ff_stack_check whenever it exists)
     for (int64_t c0 = 0; c0 < p->n; c0 += chunk_rows, ++n_chunks) {
         const int64_t nc = std::min<int64_t>(chunk_rows, p->n - c0);
         const int64_t nc_pad = round_up(nc, GEMM_BM);
@@ -1262,7 +1282,32 @@ static int ff_run_chunks(am_pipeline* p, int64_t chunk_rows, float* host_y)
             const double rounds = (double)(nc_pad / GEMM_BM) * std::max(1, m0->max_width / 256) / 256.0;
             if (std::ceil(rounds) / rounds > 1.04) n_chains = (int)max_chains;
         }
-        if (stack_ok && nc_pad <= p->stack_rows) {
+        if (stack_ok && nc_pad <= p->stack_rows && overlap_members) {
+            // Ensemble: member m + 1's stack launch goes to the other stream with its own planes and counters, so its workgroups take over
+            // the CUs member m's ragged end leaves idle (a launch ends with ~one output tile per workgroup of imbalance: 4 % of a 4x1024
+            // member at the core-test size, ten times per 10-fold ensemble).  No member waits for another: each writes plain logits to a
+            // buffer of its own, and the finish pass adds them up in member order -- the float operations of the one-after-the-other
+            // form (C = C + ...), so the same bits.  Streams alternate, so member m + 2 follows member m and re-uses its planes.
+            if (!p->ev_fork) { HIP_TRY(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming)); }
+            const int nm = (int)p->members.size();
+            const int64_t stride = (int64_t)p->stack_rows * p->acc_ld;
+            HIP_TRY(hipEventRecord(p->ev_fork, e->stream));      // the frontend's rows are written (and the previous chunk's finish has read the buffers)
+            HIP_TRY(hipStreamWaitEvent(e->stream2, p->ev_fork, 0));
+            for (int mi = 0; mi < nm; ++mi)
+                AM_TRY(ff_member_forward_stack(p, mi, nc_pad, p->d_accs.as<float>() + mi * stride, mi & 1, (mi & 1) ? e->stream2 : e->stream, EPI_LINEAR));
+            HIP_TRY(hipEventRecord(p->ev_join, e->stream2));
+            HIP_TRY(hipStreamWaitEvent(e->stream, p->ev_join, 0));
+            FinishArgs f{};
+            f.in = p->d_accs.as<float>(); f.ldin = p->acc_ld; f.n_in = nm; f.in_stride = stride;
+            f.out = p->d_out.as<float>() + c0 * m0->C; f.ldout = m0->C; f.n = nc; f.C = m0->C;
+            if (p->combine == AM_COMBINE_LOGPOST) f.member_norm = 1;
+            else if (p->has_master) f.first_scale = (float)(nm - 1);
+            f.divisor = final_divisor(p);
+            if (p->has_rpl) { f.rpl_w = p->d_rplw.as<float>(); f.rpl_b = p->d_rplb.as<float>(); f.rpl_lb = p->d_rpllb.as<float>(); }
+            if (p->has_prior) f.prior = p->d_prior.as<float>();
+            f.normalise = p->normalise;
+            AM_TRY(run_kernel(e, K_FINISH, [&] { return launch_finish(e->stream, f); }));
+        } else if (stack_ok && nc_pad <= p->stack_rows) {
             // one launch per member: a work queue over (layer, row tile, column tile) -- the layers' tails overlap, one partial round per network
             for (int mi = 0; mi < (int)p->members.size(); ++mi) {
                 AM_TRY(ff_member_forward_stack(p, mi, nc_pad, p->d_acc.as<float>()));
@@ -1327,9 +1372,10 @@ static int ff_stack_check(am_pipeline* p, bool* reran = nullptr, int64_t chunk_r
 {
     if (reran) *reran = false;
     if (p->mode != 1 || !p->used_stack || !p->d_ffsync.p) return AM_OK;
-    int flag = 0;
+    int flag = 0, flag2 = 0;
     HIP_TRY(hipMemcpy(&flag, p->d_ffsync.p, sizeof(int), hipMemcpyDeviceToHost));
-    if (!flag) return AM_OK;
+    if (p->d_ffsync2.p) HIP_TRY(hipMemcpy(&flag2, p->d_ffsync2.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (!flag && !flag2) return AM_OK;
     fprintf(stderr, "libamfwd: the single-launch Linear stack gave up on an inter-workgroup wait; repeating the pass on the per-layer launches\n");
     ++g_lstm_fallbacks;
     p->stack_off = true;

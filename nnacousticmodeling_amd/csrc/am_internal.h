@@ -107,6 +107,10 @@ struct FinishArgs {
     const float* prior;             // [C] or nullptr
     int normalise;                  // apply y - logsum(y)
     int accumulate;                 // out += result instead of out = result
+    int n_in = 1;                   // > 1: combine the members' logit buffers in + k * in_stride, k < n_in, in member order (finish_kernel)
+    int64_t in_stride = 0;          // floats between two members' buffers
+    float first_scale = 1.0f;       // member 0 is multiplied by this first (a master's weight)
+    int member_norm = 0;            // every member becomes in_k - logsum(in_k) before it is added (mean of log-posteriors)
 };
 hipError_t launch_finish(hipStream_t s, const FinishArgs& a);
 

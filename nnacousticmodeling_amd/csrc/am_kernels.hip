@@ -893,11 +893,15 @@ __device__ __forceinline__ float row_logsum(const float (&v)[NIT], int lane, int
     return lse;
 }
 
+// n_in > 1: the members of an ensemble left their logits in n_in buffers (in + k * in_stride); they are combined here in member order with
+// the float operations of the one-buffer path -- v = in_0 (* first_scale: a master's weight, NNWithRPL); v = v + in_k -- or, with
+// member_norm (the dev-mode mean of log-posteriors, predict_folds.py:207-212), v = (in_0 - logsum(in_0)); v = v + (in_k - logsum(in_k)).
 template <int NIT>
 __global__ __launch_bounds__(256) void finish_kernel(
     const float* __restrict__ in, int ldin, float* __restrict__ out, long long ldout, const int* __restrict__ row_map,
     long long n, int C, float divisor, const float* __restrict__ rpl_w, const float* __restrict__ rpl_b,
-    const float* __restrict__ rpl_lb, const float* __restrict__ prior, int normalise, int accumulate)
+    const float* __restrict__ rpl_lb, const float* __restrict__ prior, int normalise, int accumulate,
+    int n_in, long long in_stride, float first_scale, int member_norm)
 {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -909,6 +913,30 @@ __global__ __launch_bounds__(256) void finish_kernel(
     const float* src = in + row * ldin;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) { const int c = it * 64 + lane; v[it] = c < C ? src[c] : 0.0f; }
+    if (n_in > 1) {
+        if (first_scale != 1.0f) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) v[it] = v[it] * first_scale;
+        }
+        if (member_norm) {
+            const float lse = row_logsum<NIT>(v, lane, C);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) v[it] = v[it] - lse;
+        }
+        for (int k = 1; k < n_in; ++k) {
+            float w[NIT];
+            const float* sk = src + (long long)k * in_stride;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) { const int c = it * 64 + lane; w[it] = c < C ? sk[c] : 0.0f; }
+            if (member_norm) {
+                const float lse = row_logsum<NIT>(w, lane, C);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) w[it] = w[it] - lse;
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) v[it] = v[it] + w[it];
+        }
+    }
 
     if (divisor > 0.0f) {
 #pragma unroll
@@ -952,7 +980,7 @@ hipError_t launch_finish(hipStream_t s, const FinishArgs& a)
     const unsigned blocks = (unsigned)((a.n + 3) / 4);
     const int nit = (a.C + 63) / 64;
 #define AM_FINISH(N) hipLaunchKernelGGL(finish_kernel<N>, dim3(blocks), dim3(256), 0, s, a.in, a.ldin, a.out, (long long)a.ldout, a.row_map, \
-        (long long)a.n, a.C, a.divisor, a.rpl_w, a.rpl_b, a.rpl_lb, a.prior, a.normalise, a.accumulate)
+        (long long)a.n, a.C, a.divisor, a.rpl_w, a.rpl_b, a.rpl_lb, a.prior, a.normalise, a.accumulate, a.n_in, (long long)a.in_stride, a.first_scale, a.member_norm)
     if (nit <= 1) AM_FINISH(1);
     else if (nit <= 2) AM_FINISH(2);
     else if (nit <= 4) AM_FINISH(4);

@@ -423,4 +423,14 @@ def test_ten_fold_ensemble_config_size(engine, real_ft_path, real_priors):
         lo = p.forward_ff(x[:mid + 5], None, mid, 0, 5)
         hi = p.forward_ff(x[mid - 5:], None, n - mid, 5, 0)
         assert np.array_equal(lo, y[:mid]) and np.array_equal(hi, y[mid:])
+        # the device-resident pass runs the members two at a time on alternating streams, each into a logit buffer of its own, and adds
+        # them up in member order in the finish pass; the one-shot call above runs them one after the other (C = C + ...): the same bits
+        p.ff_upload(x, None, n, 0, 0)
+        engine.profile(True)
+        engine.profile_reset()
+        p.ff_run()
+        prof = engine.profile_read()
+        engine.profile(False)
+        assert prof["gemm_stack"][0] == K and prof["finish"][0] == 1, prof      # (the overlapped form: ONE finish launch for all members)
+        assert np.array_equal(p.ff_download(), y)
         p.close()
