@@ -1656,10 +1656,12 @@ __device__ __forceinline__ bool persist_products(const float* up, unsigned row_u
         const int issued = (b + NBUF - 1 < NBT) ? b + NBUF - 1 : NBT;     // tiles requested so far
         wait_vmcnt(NT * (issued - (b + 1)));                               // tile b has landed (this wave's part)
         __builtin_amdgcn_s_barrier();                                      // ... everybody's; and everyone has left tile b-1
-        if (b + NBUF - 1 < NBT) {
-            if (LAT && NBU >= NBUF - 1 && b + NBUF - 1 == NBU) ok = lat_wait() && ok;
-            issue(b + NBUF - 1);
-        }
+        // The request of tile b + NBUF - 1 goes out BETWEEN this batch's MFMAs, and at a different sub-step in the two waves that share a SIMD
+        // (K half 0: behind sub-step 0, K half 1: behind sub-step 2): every wave of the workgroup leaves the barrier at the same moment, and
+        // issued right there the NT LDS-DMA instructions of both waves (~75 cycles each) find the matrix pipe idle; staggered, one wave's
+        // issue runs beside the other's MFMAs.
+        const bool due = b + NBUF - 1 < NBT;
+        if (due && LAT && NBU >= NBUF - 1 && b + NBUF - 1 == NBU) ok = lat_wait() && ok;
         if (b + 2 == NBT || (NBT == 1 && b == 0)) mid();
         const float* sa = fbase + (b % NBUF) * BUF_FLOATS;
         f32x4 pb[NT];
@@ -1678,6 +1680,7 @@ __device__ __forceinline__ bool persist_products(const float* up, unsigned row_u
 #pragma unroll
                     for (int r = 0; r < NT; ++r)
                         pb[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s][r][j], (b < NBU ? wu[b < NBU ? b : 0][s][j] : wl[b < NBU ? 0 : b - NBU][s][j]), pb[r], 0, 0, 0);
+            if (due) issue(b + NBUF - 1);   // (few rows: the batch is short, the request goes out behind its MFMAs' issue)
         } else {         // (double-buffering the fragments across sub-steps costs 16 VGPRs the weights need, and measured no gain)
 #pragma unroll
             for (int s = 0; s < LSTM_KS; ++s) {
@@ -1689,6 +1692,7 @@ __device__ __forceinline__ bool persist_products(const float* up, unsigned row_u
 #pragma unroll
                     for (int r = 0; r < NT; ++r)
                         pb[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][j], (b < NBU ? wu[b < NBU ? b : 0][s][j] : wl[b < NBU ? 0 : b - NBU][s][j]), pb[r], 0, 0, 0);
+                if (due && s == (kh ? 2 : 0)) issue(b + NBUF - 1);
             }
         }
 #pragma unroll
