@@ -1713,7 +1713,7 @@ constexpr int PERSIST_SGLD = 20;   // gate-exchange row stride: 16 units + 16 B 
 
 template <int NBU, int NBL, int NT>
 __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const LstmPersistLayer& Ly, int li, int gidx, int ut, int t, int n_act, int row0,
-                                             const f32x4 (&wu)[NBU ? NBU : 1][LSTM_KS], const f32x4 (&wl)[NBL][LSTM_KS],
+                                             unsigned off_t, unsigned off_p, const f32x4 (&wu)[NBU ? NBU : 1][LSTM_KS], const f32x4 (&wl)[NBL][LSTM_KS],
                                              float* smem, int tile_rows, int* s_flag)
 {
     constexpr int ROWS = NT * 16;
@@ -1724,8 +1724,8 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
     const int U_pad = a.U_pad, ldg = 4 * U_pad;
     const int rows_valid = n_act - row0;                       // > 0
     const int slot0 = a.slot_base + row0;                       // first utterance slot of this group's rows
-    const unsigned r_t = (unsigned)(a.step_off[t] + slot0);     // its packed row at step t
-    const unsigned r_p = t > 0 ? (unsigned)(a.step_off[t - 1] + slot0) : 0u;   // ... and at step t - 1 (h and c of the previous step)
+    const unsigned r_t = off_t + (unsigned)slot0;               // its packed row at step t (off_t = step_off[t], fetched a step ahead by the caller)
+    const unsigned r_p = off_p + (unsigned)slot0;               // ... and at step t - 1 (h and c of the previous step; unused at t == 0)
     persist_stamp(a, gidx, ut, t, 0);
     if (NBU) {   // upward product: needs step t of the layer below (which runs ahead: normally no wait at all)
         if (!persist_wait(a, a.L[li - 1].group0, a.L[li - 1].n_groups, t, s_flag)) return false;
@@ -1807,6 +1807,265 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
     return true;
 }
 
+// The step of an upper layer of a 512-unit stack (four 128-k batches per product) on 256-k tiles: ONE pipeline over both products, two tile
+// buffers of 64 rows x 1 KB, and every memory round trip of the step's chain requested before it is needed.
+// The timeline of the 128-k form showed a FIXED ~7.4 us per step on top of the MFMA time, whatever the row count (16 rows: 7.4 us a step; 192
+// rows: 21 us against 13.7 us of matrix work): the counter poll at the top, the cold start of each product's tile stream, the lateral poll, the
+// gate exchange and the publish -- all in series.  Here:
+//   T0 = h_below[t][0:256)  T1 = h_below[t][256:512)  T2 = h[t-1][0:256)  T3 = h[t-1][256:512);  tile i lives in buffer (i + 1) & 1
+//   top   : [T0 already travelling: requested by step t-1, see below | else upward wait, request T0]  lateral counters peeked  request T1
+//   b = 0 : T0 landed, barrier, batches U0 U1
+//   b = 1 : T1 landed, lateral wait (skips the poll when the peek already saw the arrivals; ends in the barrier), cell state requested,
+//           step t+1's upward counters peeked, T2 requested between the MFMAs, batches U2 U3
+//   b = 2 : T2 landed, barrier, T3 requested between the MFMAs, batches L0 L1
+//   b = 3 : T3 landed, barrier, if the peek saw step t+1 of the layer below: T0 OF STEP t+1 requested (buffer 1 is free, the gate exchange
+//           uses buffer 0), batches L2 L3
+//   barrier, gates, stores, publish
+// so a step that finds its upward input ready (the normal case: lower layers run ahead) starts with its first tile in LDS and never polls.
+// A DMA instruction moves one whole tile row (64 lanes x 16 B): the clamp to the last valid row is per instruction and the per-lane part of
+// the address is the swizzled chunk alone.  Summation order unchanged: 64-k chains from zero per K half, folded in batch order U0..U3, L0..L3.
+struct PersistNext { int nt, row0, n_act; unsigned off; };   // a group's share of a step: tiles (<= 0: none), first row, active rows, step_off[t]
+
+__device__ __forceinline__ bool persist_wait_seen(const LstmPersistArgs& a, int first, int n, unsigned seen, unsigned target, int* s_flag)
+{
+    if (threadIdx.x < 64) {
+        bool ok = true;
+        if ((int)threadIdx.x < n && seen < target) {
+            const unsigned* c = a.counters + first + threadIdx.x;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            int it = 0;
+            while (ld_agent_u32(c) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++it & 63) == 0 && (__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                                        __builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)LSTM_P_TIMEOUT)) { ok = false; break; }
+            }
+        }
+        if (!ok) { __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *s_flag = 1; }
+    }
+    __syncthreads();
+    return *s_flag == 0;
+}
+
+template <int NT>
+__device__ __forceinline__ bool persist_step_wide(const LstmPersistArgs& a, const LstmPersistLayer& Ly, int li, int gidx, int ut, int t, int n_act, int row0,
+                                                  unsigned off_t, unsigned off_p, const PersistNext nx, int& have,
+                                                  const f32x4 (&wu)[4][LSTM_KS], const f32x4 (&wl)[4][LSTM_KS], float* smem, int* s_flag)
+{
+    constexpr int ROWS = NT * 16;
+    constexpr int TLD = 2 * LSTM_KB;                 // floats per tile row
+    constexpr bool THIN = NT <= 2;                   // 32-row tiles: every tile of the step has a buffer of its own
+    constexpr int Q = 32 * TLD;                      // a 32 KB quarter of the tile space, in floats
+    // tile -> offset.  Thick: T0, T2 in the upper half, T1, T3 in the lower.  Thin: T0, T1 in the upper half's quarters, T2, T3 in the lower half's.
+    // Either way a step's first tile(s) live in the upper half and the gate exchange in the lower, so the step before can request them.
+    constexpr int OFF0 = 2 * Q, OFF1 = THIN ? 3 * Q : 0, OFF2 = THIN ? 0 : 2 * Q, OFF3 = THIN ? Q : 0;
+    constexpr int NI = 2 * NT;                       // DMA instructions per wave and tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gate = wave & 3, kh = wave >> 2;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int U_pad = a.U_pad;
+    const int rows_valid = n_act - row0;                       // > 0
+    const int slot0 = a.slot_base + row0;
+    const unsigned r_t = off_t + (unsigned)slot0;
+    const unsigned r_p = off_p + (unsigned)slot0;              // (t == 0: unused)
+    const bool lat = t > 0;
+    const LstmPersistLayer& Lb = a.L[li - 1];
+    // tile row of instruction e: wave + 8 e, so row & 15 takes two values per wave
+    // (buffer form of the LDS-DMA: the per-lane part of the address is one of two 32-bit offsets, everything else is scalar -- no 64-bit vector
+    // address per instruction, which the register budget of this kernel does not have)
+    const int loff0 = 16 * (lane ^ wave);             // tile row wave + 8 e: row & 15 is wave or wave + 8, the odd instructions' offset is loff0 ^ 128
+    const __amdgpu_buffer_rsrc_t uprs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.Hin, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.H, 0, 0x7fffffff, 0x00020000);
+    auto dma_row = [&](__amdgpu_buffer_rsrc_t rs, unsigned byte0, int rows_v, float* buf, int e) {
+        const int row = wave + 8 * e;
+        const int srow = row < rows_v ? row : rows_v - 1;
+        int lo = loff0;
+        asm volatile("" : "+v"(lo));                   // (recomputed per instruction rather than held: the kernel has no register to spare)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, AM_LDS_PTR(buf + row * TLD), 16, (e & 1) ? (lo ^ 128) : lo, (int)(byte0 + (unsigned)srow * (unsigned)U_pad * 4u), 0, 16 /* sc1 */);
+    };
+    auto dma_tile = [&](__amdgpu_buffer_rsrc_t rs, unsigned byte0, float* buf) {
+#pragma unroll
+        for (int e = 0; e < NI; ++e) dma_row(rs, byte0, rows_valid, buf, e);
+    };
+    const unsigned up0 = r_t * (unsigned)U_pad * 4u;     // byte offsets into the planes (< 2 GB: am_lstm_upload's bound on the persistent form)
+    const unsigned lat0 = r_p * (unsigned)U_pad * 4u;
+    constexpr unsigned TB = TLD * 4u;                    // bytes of a tile row: the second 256-k tile of a product starts there
+    persist_stamp(a, gidx, ut, t, 0);
+    if (have < 1) {
+        if (!persist_wait(a, Lb.group0, Lb.n_groups, t, s_flag)) return false;
+        dma_tile(uprs, up0, smem + OFF0);
+    }
+    const bool t1_here = have < 2;
+    if (t1_here) dma_tile(uprs, up0 + TB, smem + OFF1);
+    persist_stamp(a, gidx, ut, t, 1);
+    const int erow = tid >> 2, quad = tid & 3;
+    const bool live = erow < ROWS && erow < rows_valid;
+    f32x4 cq = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.Cst, 0, 0x7fffffff, 0x00020000);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int r = 0; r < NT; ++r) acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    // fragment of (row r*16 + l15, sub-step s): float index l15*TLD + kh*64 + 4*(((4 s + lq) ^ l15) & 15) = la ^ (16 s) -- one register, not one per sub-step
+    const unsigned la = (unsigned)(l15 * TLD + kh * (LSTM_KB / 2) + 4 * ((lq ^ l15) & 15));
+    // Counters looked at ahead of their wait: wave 0 sends counter and target of group min(lane, n - 1) to LDS by DMA (no register is held through
+    // the MFMA phases; the 16 KB above the tile space are free), and compares when the wait comes.
+    unsigned* pk = (unsigned*)(smem + 4 * Q);   // [0] lateral counters [64] their targets [128] upward counters of step t + 1 [192] their targets
+    auto peek = [&](int first, int n, int tcol, unsigned* dst) {
+        if (wave == 0) {
+            const int j = first + (lane < n ? lane : n - 1);
+            __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(a.counters + j), AM_LDS_PTR(dst), 4, 0, 16 /* sc1 */);
+            __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(a.cum + (size_t)j * a.T + tcol), AM_LDS_PTR(dst + 64), 4, 0, 0);
+        }
+    };
+    auto peek_lateral = [&] { if (lat) peek(Ly.group0, Ly.n_groups, t - 1, pk); };
+    const bool want_next = lat && nx.nt > 0 && (!THIN || nx.nt <= 2);   // (rows only ever decrease; the thin form's counted wait assumes a thin successor)
+    int pre = 0;
+    have = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        if (b >= 2 && !lat) break;
+        // tile b has landed (this wave's part)
+        if (b == 0) { if (t1_here) wait_vmcnt(NI); else wait_vmcnt(0); }
+        else if (b == 2 && THIN) wait_vmcnt(NI);                   // T3 was requested with T2 and still travels
+        else if (b == 3 && THIN && pre != 0) { if (nx.nt == 1) wait_vmcnt(4); else wait_vmcnt(8); }   // ... and so do step t + 1's two tiles, requested at b == 2
+        else wait_vmcnt(0);
+        if (b == 1 && lat) {                                       // step t-1 of every group of this layer; the wait ends in the barrier
+            unsigned seenL = 0, tgtL = 0;
+            if (tid < 64) { seenL = pk[lane]; tgtL = pk[64 + lane]; }
+            if (!persist_wait_seen(a, Ly.group0, Ly.n_groups, seenL, tgtL, s_flag)) return false;
+            // few rows: registers to spare and short batches -- the previous cell state is requested here (many rows: under the last tile's MFMAs)
+            if (THIN && live) cq = ld_sc1_b128(crs, ((r_p + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u);
+            if (want_next) peek(Lb.group0, Lb.n_groups, t + 1, pk + 128);   // (both before the tiles: b == 2's counted wait must cover them)
+            if (THIN) { dma_tile(hrs, lat0, smem + OFF2); dma_tile(hrs, lat0 + TB, smem + OFF3); }   // few rows: the step is a chain of latencies, both lateral tiles leave at once
+        } else {
+            if (b == 2 && tid < 64) {                              // has the layer below finished step t + 1?
+                const bool all = want_next && __builtin_amdgcn_ballot_w64(pk[128 + lane] < pk[192 + lane]) == 0ull;
+                if (tid == 0) s_flag[1] = (want_next && all) ? 1 : 0;
+            }
+            __builtin_amdgcn_s_barrier();
+            if (b == 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pre = __builtin_amdgcn_readfirstlane(s_flag[1]); }
+            if (!THIN && b == 3 && live) cq = ld_sc1_b128(crs, ((r_p + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u);
+        }
+        if (b == 2) persist_stamp(a, gidx, ut, t, 2);
+        const bool due = !THIN && lat && (b == 1 || b == 2);       // the buffer of tile b + 1 is free: everybody is past tile b - 1
+        const unsigned nsrc = b == 1 ? lat0 : lat0 + TB;
+        float* nbuf = smem + (b == 1 ? OFF2 : OFF3);
+        // the first tile of step t + 1 -- both tiles if that step is a thin one.  Its geometry is step t + 1's, not a constant of this instantiation.
+        const bool due_next = b == (THIN ? 2 : 3) && pre != 0;     // (few rows: a tile earlier -- its buffers are free, and the publish must not wait for it)
+        const unsigned up_next = (nx.off + (unsigned)(a.slot_base + nx.row0)) * (unsigned)U_pad * 4u;
+        const int rows_next = nx.n_act - nx.row0;
+        unsigned lb = la + (unsigned)(b == 0 ? OFF0 : b == 1 ? OFF1 : b == 2 ? OFF2 : OFF3);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4 pb[NT];
+#pragma unroll
+            for (int r = 0; r < NT; ++r) pb[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            const int wi = 2 * (b & 1) + q;
+            if (NT <= 2) {
+                f32x4 af[LSTM_KS][NT];
+#pragma unroll
+                for (int s = 0; s < LSTM_KS; ++s)
+#pragma unroll
+                    for (int r = 0; r < NT; ++r) af[s][r] = *(const f32x4*)(smem + (lb ^ (16u * s)) + r * 16 * TLD + q * LSTM_KB);
+#pragma unroll
+                for (int s = 0; s < LSTM_KS; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < NT; ++r)
+                            pb[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s][r][j], (b < 2 ? wu[wi][s][j] : wl[wi][s][j]), pb[r], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < LSTM_KS; ++s) {
+                    f32x4 af[NT];
+                    asm volatile("" : "+v"(lb));
+                    const float* pa = smem + (lb ^ (16u * s)) + q * LSTM_KB;
+#pragma unroll
+                    for (int r = 0; r < NT; ++r) af[r] = *(const f32x4*)(pa + r * 16 * TLD);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < NT; ++r)
+                            pb[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][j], (b < 2 ? wu[wi][s][j] : wl[wi][s][j]), pb[r], 0, 0, 0);
+                    // the next tile's request, spread over this wave's sub-steps of one 128-k batch -- K half 0 under the first, K half 1 under the second
+                    if (due && q == kh) {
+#pragma unroll
+                        for (int e = 0; e < NI; ++e) if ((e & 3) == s) dma_row(hrs, nsrc, rows_valid, nbuf, e);
+                    }
+                }
+            }
+            if (b == 0 && q == 0) peek_lateral();
+            if (due_next && (THIN ? q == 0 : q == kh)) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (e < 2 * nx.nt) dma_row(uprs, up_next, rows_next, smem + 2 * Q, e);
+                if (nx.nt <= 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (e < 2 * nx.nt) dma_row(uprs, up_next + TB, rows_next, smem + 3 * Q, e);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NT; ++r) acc[r] += pb[r];
+        }
+        if (due_next) have = nx.nt <= 2 ? 2 : 1;
+    }
+    __syncthreads();
+    persist_stamp(a, gidx, ut, t, 4);
+    float* sg = smem;   // the lower half (at most 40 KB of it): the upper half may be receiving step t + 1's first tiles
+#pragma unroll
+    for (int r = 0; r < NT; ++r)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+            sg[((kh * 4 + gate) * ROWS + r * 16 + lq * 4 + reg) * PERSIST_SGLD + l15] = acc[r][reg];
+    f32x4 gq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        gq[k] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        if (live) gq[k] = *(const f32x4*)(Ly.bias + ut * 64 + k * 16 + 4 * quad);
+    }
+    __syncthreads();
+    if (live) {
+        f32x4 pre4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            pre4[k] = (*(const f32x4*)(sg + ((0 * 4 + k) * ROWS + erow) * PERSIST_SGLD + 4 * quad) + *(const f32x4*)(sg + ((1 * 4 + k) * ROWS + erow) * PERSIST_SGLD + 4 * quad)) + gq[k];
+        f32x4 cn, hn;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float ga = am_tanh_rec(pre4[0][u]);
+            const float gi = am_sigmoid_rec(pre4[1][u]);
+            const float gf = am_sigmoid_rec(pre4[2][u]);
+            const float go = am_sigmoid_rec(pre4[3][u]);
+            const float ai = ga * gi;
+            const float fc = gf * cq[u];
+            const float c = ai + fc;
+            cn[u] = c;
+            hn[u] = go * am_tanh_rec(c);
+        }
+        st_sc1_b128(crs, ((r_t + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u, cn);
+        st_sc1_b128(hrs, ((r_t + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u, hn);
+    }
+    persist_stamp(a, gidx, ut, t, 5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(a.counters + gidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    persist_stamp(a, gidx, ut, t, 6);
+    return true;
+}
+
+// upper layers of a 512-unit stack take the 256-k-tile form (AM_PERSIST_WIDE=0 at build time keeps the 128-k form for A/B timing)
+#ifndef AM_PERSIST_WIDE
+#define AM_PERSIST_WIDE 1
+#endif
+template <int NBU, int NBL, int NT>
+__device__ __forceinline__ bool persist_step_any(const LstmPersistArgs& a, const LstmPersistLayer& Ly, int li, int gidx, int ut, int t, int n_act, int row0,
+                                                 unsigned off_t, unsigned off_p, const PersistNext nx, int& have,
+                                                 const f32x4 (&wu)[NBU ? NBU : 1][LSTM_KS], const f32x4 (&wl)[NBL][LSTM_KS],
+                                                 float* smem, int tile_rows, int* s_flag)
+{
+    if constexpr (AM_PERSIST_WIDE && NBU == 4 && NBL == 4 && NT <= 4) return persist_step_wide<NT>(a, Ly, li, gidx, ut, t, n_act, row0, off_t, off_p, nx, have, wu, wl, smem, s_flag);
+    else return persist_step<NBU, NBL, NT>(a, Ly, li, gidx, ut, t, n_act, row0, off_t, off_p, wu, wl, smem, tile_rows, s_flag);
+}
+
 template <int NBU, int NBL, int NTMAX>
 __device__ __forceinline__ void persist_body(const LstmPersistArgs& a, const LstmPersistLayer& Ly, int li, int gidx, int ut, float* smem, int* s_flag)
 {
@@ -1835,26 +2094,42 @@ __device__ __forceinline__ void persist_body(const LstmPersistArgs& a, const Lst
     // this launch's steps [t_begin, t_end): a launch that starts at t_begin > 0 finds h, c and the arrival counters as the launch for the steps
     // before it left them (its first waits are already satisfied)
     const int t_end = a.t_end > 0 ? a.t_end : a.T;
-    int n_next = local_rows(a.n_active[a.t_begin]);
-    for (int t = a.t_begin; t < t_end; ++t) {
-        const int n_act = n_next;
-        n_next = t + 1 < t_end ? local_rows(a.n_active[t + 1]) : 0;   // requested a whole step ahead: the scalar load's latency is off the chain
-        const int tiles = (n_act + 15) >> 4;
-        if (tiles <= 0) break;
-        const int q = (tiles + NG - 1) / NG;            // <= NTMAX (host plan)
-        const int tile0 = g * q;
-        int nt = tiles - tile0;
+    // the group's share of a step with n active rows: q = ceil(tiles / NG) tiles from tile g q on (q <= NTMAX by the host plan)
+    auto share = [&](int n_raw, unsigned off) {
+        const int n = local_rows(n_raw);
+        const int tiles = (n + 15) >> 4;
+        const int q = (tiles + NG - 1) / NG;
+        int nt = tiles - g * q;
         if (nt > q) nt = q;
+        return PersistNext{tiles > 0 ? nt : 0, g * q * 16, n, off};
+    };
+    // n_active and step_off travel two steps ahead of their use (scalar loads; consumed the iteration after they were requested): the ~1 us between
+    // a step's publish and the next step's first instruction that the timeline showed was these loads' latency
+    int raw_n = a.n_active[a.t_begin];
+    unsigned raw_off = (unsigned)a.step_off[a.t_begin];
+    PersistNext nx = share(raw_n, raw_off);
+    raw_n = a.t_begin + 1 < t_end ? a.n_active[a.t_begin + 1] : 0;
+    raw_off = a.t_begin + 1 < t_end ? (unsigned)a.step_off[a.t_begin + 1] : 0u;
+    unsigned off_p = a.t_begin > 0 ? (unsigned)a.step_off[a.t_begin - 1] : 0u;
+    int have = 0;                                       // tiles of the step's upward product the step before has already requested (256-k form)
+    for (int t = a.t_begin; t < t_end; ++t) {
+        const PersistNext cur = nx;
+        nx = share(raw_n, raw_off);
+        raw_n = t + 2 < t_end ? a.n_active[t + 2] : 0;
+        raw_off = t + 2 < t_end ? (unsigned)a.step_off[t + 2] : 0u;
+        const int n_act = cur.n_act, nt = cur.nt, row0 = cur.row0;
+        const unsigned off_t = cur.off, off_prev = off_p;
+        off_p = off_t;
+        if (n_act <= 0) break;
         if (nt <= 0) continue;                          // nothing for this group at this step (the host's arrival table knows)
         bool ok = true;
-        const int row0 = tile0 * 16;
         switch (nt) {
-        case 1: ok = persist_step<NBU, NBL, 1>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, smem, NTMAX * 16, s_flag); break;
-        case 2: ok = persist_step<NBU, NBL, 2>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, smem, NTMAX * 16, s_flag); break;
-        case 3: ok = persist_step<NBU, NBL, 3>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, smem, NTMAX * 16, s_flag); break;
-        case 4: ok = persist_step<NBU, NBL, 4>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, smem, NTMAX * 16, s_flag); break;
-        case 5: if (NTMAX >= 5) ok = persist_step<NBU, NBL, NTMAX >= 5 ? 5 : 1>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, smem, NTMAX * 16, s_flag); break;
-        case 6: if (NTMAX >= 6) ok = persist_step<NBU, NBL, NTMAX >= 6 ? 6 : 1>(a, Ly, li, gidx, ut, t, n_act, row0, wu, wl, smem, NTMAX * 16, s_flag); break;
+        case 1: ok = persist_step_any<NBU, NBL, 1>(a, Ly, li, gidx, ut, t, n_act, row0, off_t, off_prev, nx, have, wu, wl, smem, NTMAX * 16, s_flag); break;
+        case 2: ok = persist_step_any<NBU, NBL, 2>(a, Ly, li, gidx, ut, t, n_act, row0, off_t, off_prev, nx, have, wu, wl, smem, NTMAX * 16, s_flag); break;
+        case 3: ok = persist_step_any<NBU, NBL, 3>(a, Ly, li, gidx, ut, t, n_act, row0, off_t, off_prev, nx, have, wu, wl, smem, NTMAX * 16, s_flag); break;
+        case 4: ok = persist_step_any<NBU, NBL, 4>(a, Ly, li, gidx, ut, t, n_act, row0, off_t, off_prev, nx, have, wu, wl, smem, NTMAX * 16, s_flag); break;
+        case 5: if (NTMAX >= 5) ok = persist_step<NBU, NBL, NTMAX >= 5 ? 5 : 1>(a, Ly, li, gidx, ut, t, n_act, row0, off_t, off_prev, wu, wl, smem, NTMAX * 16, s_flag); break;
+        case 6: if (NTMAX >= 6) ok = persist_step<NBU, NBL, NTMAX >= 6 ? 6 : 1>(a, Ly, li, gidx, ut, t, n_act, row0, off_t, off_prev, wu, wl, smem, NTMAX * 16, s_flag); break;
         default: break;
         }
         if (!ok) return;
@@ -1868,8 +2143,8 @@ template <int NB>
 __global__ __launch_bounds__(512, 2) void lstm_persist_kernel(const LstmPersistArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float persist_smem[];
-    __shared__ int s_flag;
-    if (threadIdx.x == 0) s_flag = 0;
+    __shared__ int s_flag[2];   // [0] the pass has been aborted; [1] scratch of the 256-k step form
+    if (threadIdx.x == 0) { s_flag[0] = 0; s_flag[1] = 0; }
     __syncthreads();
     // role: blocks b and b + n_groups_total share a group's neighbour tiles; b % n_groups_total = group, so with 8 groups the
     // 32 workgroups of a group sit on one XCD under round-robin placement (speed only)
@@ -1878,8 +2153,8 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_kernel(const LstmPersistA
 #pragma unroll
     for (int l = 1; l < LSTM_MAX_LAYERS; ++l) if (l < a.n_layers && gidx >= a.L[l].group0) li = l;
     const LstmPersistLayer& Ly = a.L[li];
-    if (li > 0) persist_body<NB, NB, lstm_persist_ntmax(NB, true)>(a, Ly, li, gidx, ut, persist_smem, &s_flag);
-    else persist_body<0, NB, lstm_persist_ntmax(NB, false)>(a, Ly, li, gidx, ut, persist_smem, &s_flag);
+    if (li > 0) persist_body<NB, NB, lstm_persist_ntmax(NB, true)>(a, Ly, li, gidx, ut, persist_smem, s_flag);
+    else persist_body<0, NB, lstm_persist_ntmax(NB, false)>(a, Ly, li, gidx, ut, persist_smem, s_flag);
 }
 
 
