@@ -14,6 +14,7 @@
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <chrono>
 #include <vector>
 
 using namespace am;
@@ -2211,6 +2212,7 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
     // launch gaps included, without the cost of an event pair per launch)
     for (int sl : {62, 63}) if (!e->ev[sl]) HIP_TRY(hipEventCreate(&e->ev[sl]));
     HIP_TRY(hipEventRecord(e->ev[62], e->stream));
+    const auto host_t0 = std::chrono::steady_clock::now();
     if (a.compact && fs_ok && fs_fits) {
         // frame-synchronous: slots = utterances by length (longest first); step k advances the first n_active slots
         std::vector<int> order(n_utts);
@@ -2218,16 +2220,49 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return offsets[x + 1] - offsets[x] > offsets[y + 1] - offsets[y]; });
         AM_TRY(upload_raw(e, d->d_slot, order.data(), order.size()));
         a.slot_utt = d->d_slot.as<int>();
-        AM_TRY(run_kernel(e, K_VITERBI, [&] { return launch_viterbi_fs_init(e->stream, a, n_utts); }));
+        const bool as_graph = env_int("AM_VITERBI_GRAPH", 0) != 0 && !e->profile;   // experiment: the launch sequence as one graph launch
+        if (as_graph) HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+        int rc = run_kernel(e, K_VITERBI, [&] { return launch_viterbi_fs_init(e->stream, a, n_utts); });
         int active = n_utts;
-        for (int64_t k = 0; k < longest; ++k) {
+        std::vector<hipEvent_t> seg_ev;                       // diagnostic (AM_VITERBI_TIMING=2): device time per 64 frames
+        std::vector<int> seg_active;
+        const bool seg_timing = env_int("AM_VITERBI_TIMING", 0) == 2 && !as_graph;
+        for (int64_t k = 0; k < longest && rc == AM_OK; ++k) {
             while (active > 0 && offsets[order[active - 1] + 1] - offsets[order[active - 1]] <= k) --active;
-            AM_TRY(run_kernel(e, K_VITERBI, [&] { return launch_viterbi_fs_step(e->stream, a, (int)k, active); }));
+            if (seg_timing && k % 64 == 0) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); HIP_TRY(hipEventRecord(ev, e->stream)); seg_ev.push_back(ev); seg_active.push_back(active); }
+            rc = run_kernel(e, K_VITERBI, [&] { return launch_viterbi_fs_step(e->stream, a, (int)k, active); });
         }
-        AM_TRY(run_kernel(e, K_VITERBI, [&] { return launch_viterbi_fs_trace(e->stream, a, n_utts); }));
+        if (seg_timing && rc == AM_OK) {
+            hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); HIP_TRY(hipEventRecord(ev, e->stream)); seg_ev.push_back(ev);
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            for (size_t i = 0; i + 1 < seg_ev.size(); ++i) {
+                float ms = 0.0f; (void)hipEventElapsedTime(&ms, seg_ev[i], seg_ev[i + 1]);
+                const int64_t nf = std::min<int64_t>(64, longest - (int64_t)i * 64);
+                fprintf(stderr, "libamfwd: frames %4zu..: %3d active at the start, %.3f ms, %.1f us per frame\n", i * 64, seg_active[i], ms, ms * 1e3 / nf);
+            }
+            for (hipEvent_t ev2 : seg_ev) (void)hipEventDestroy(ev2);
+        }
+        if (rc == AM_OK) rc = run_kernel(e, K_VITERBI, [&] { return launch_viterbi_fs_trace(e->stream, a, n_utts); });
+        if (as_graph) {
+            hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+            const hipError_t ce = hipStreamEndCapture(e->stream, &g);
+            if (rc == AM_OK && ce != hipSuccess) rc = fail(AM_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+            if (rc == AM_OK && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) rc = fail(AM_EHIP, "hipGraphInstantiate failed");
+            if (rc == AM_OK) {
+                HIP_TRY(hipEventRecord(e->ev[62], e->stream));   // (the capture and instantiation are host time; the device time is the replay's)
+                if (hipGraphLaunch(ge, e->stream) != hipSuccess) rc = fail(AM_EHIP, "hipGraphLaunch failed");
+                HIP_TRY(hipStreamSynchronize(e->stream));
+            }
+            if (ge) (void)hipGraphExecDestroy(ge);
+            if (g) (void)hipGraphDestroy(g);
+        }
+        AM_TRY(rc);
     } else
     AM_TRY(run_kernel(e, K_VITERBI, [&] { return launch_viterbi(e->stream, a, n_utts); }));
     HIP_TRY(hipEventRecord(e->ev[63], e->stream));
+    if (env_int("AM_VITERBI_TIMING", 0) != 0)   // diagnostic: how long the host took to enqueue the launch sequence
+        fprintf(stderr, "libamfwd: decode launch sequence enqueued in %.3f ms (host)\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count());
     std::vector<int> hb(std::max<int64_t>(N, 1)), he(std::max<int64_t>(N, 1)), ht(std::max<int64_t>(N, 1));
     if (N > 0) {
         HIP_TRY(hipMemcpyAsync(hb.data(), d->seg_begin.p, sizeof(int) * N, hipMemcpyDeviceToHost, e->stream));

@@ -2931,24 +2931,30 @@ __global__ __launch_bounds__(1024) void viterbi_kernel(const ViterbiArgs a)
 // and every thread handles two triphones per trip (twice the loads in flight: the tail of the run belongs to the longest
 // utterances, one CU each, where the per-CU memory parallelism is the limit).  Same arithmetic, same comparisons, same
 // tie-breaking as viterbi_kernel: bit-identical segmentations.
-__device__ __forceinline__ void viterbi_tri_update(const i32x4 c0, const f32x4 c1, const i32x4 q, const int t2s, const float* __restrict__ p,
-                                                    const float* __restrict__ lp1, float PIP, int k, i32x4& nq, int& nt2, float& po)
+// (the arithmetic of one triphone's update on operands already in registers: `pn` = p[node], e0..e2 = the frame's log-posteriors of its states)
+__device__ __forceinline__ void viterbi_tri_apply(const i32x4 c0, const f32x4 c1, const i32x4 q, const int t2s, const float pn,
+                                                   const float e0, const float e1, const float e2, float PIP, int k, i32x4& nq, int& nt2, float& po)
 {
-    const int node = c0[0] & 0xffff, col0 = (unsigned)c0[0] >> 16, col1 = c0[1] & 0xffff, col2 = (unsigned)c0[1] >> 16;
     const float sl0 = __int_as_float(c0[2]), sl1 = __int_as_float(c0[3]), sl2 = c1[0];
     const float tr0 = c1[1], tr1 = c1[2], tr2 = c1[3];
     const float q0 = __int_as_float(q[0]), q1 = __int_as_float(q[1]), q2 = __int_as_float(q[2]);
     const int t0s = q[3] & 0xffff, t1s = (unsigned)q[3] >> 16;   // entry times + 1
-    const float pIn = p[node] + PIP;
+    const float pIn = pn + PIP;
     const float st0 = q0 + sl0, st1 = q1 + sl1, st2 = q2 + sl2;
     const float go0 = pIn, go1 = q0 + tr0, go2 = q1 + tr1;
-    const float e0 = lp1[col0], e1 = lp1[col1], e2 = lp1[col2];
     float n0, n1, n2; int nt0, nt1;
     if (go2 > st2) { n2 = go2 + e2; nt2 = t1s; } else { n2 = st2 + e2; nt2 = t2s; }
     if (go1 > st1) { n1 = go1 + e1; nt1 = t0s; } else { n1 = st1 + e1; nt1 = t1s; }
     if (go0 > st0) { n0 = go0 + e0; nt0 = k; } else { n0 = st0 + e0; nt0 = t0s; }   // k = (k - 1) + 1
     nq[0] = __float_as_int(n0); nq[1] = __float_as_int(n1); nq[2] = __float_as_int(n2); nq[3] = nt0 | (nt1 << 16);
     po = n2 + tr2;
+}
+
+__device__ __forceinline__ void viterbi_tri_update(const i32x4 c0, const f32x4 c1, const i32x4 q, const int t2s, const float* __restrict__ p,
+                                                    const float* __restrict__ lp1, float PIP, int k, i32x4& nq, int& nt2, float& po)
+{
+    const int node = c0[0] & 0xffff, col0 = (unsigned)c0[0] >> 16, col1 = c0[1] & 0xffff, col2 = (unsigned)c0[1] >> 16;
+    viterbi_tri_apply(c0, c1, q, t2s, p[node], lp1[col0], lp1[col1], lp1[col2], PIP, k, nq, nt2, po);
 }
 
 __global__ __launch_bounds__(1024) void viterbi_compact_kernel(const ViterbiArgs a)
@@ -3042,6 +3048,9 @@ __global__ __launch_bounds__(256) void viterbi_fs_init_kernel(const ViterbiArgs 
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.B; i += gridDim.x * 256) p[i] = a.p0[i];
 }
 
+// Frame-synchronous triphone update, operands gathered from global memory (the tail of a run, and graphs whose two gather arrays do not fit LDS).
+// Tried (round 3): one thread = two triphones x S utterance slots, the 32 B of graph constants fetched once per S slots instead of once per
+// (slot, triphone) -- 292 (S = 4) against 269 us per frame at 192 active utterances: the constants are cheap L2 hits, the registers cost occupancy.
 __global__ __launch_bounds__(256) void viterbi_fs_tri_kernel(const ViterbiArgs a, int k)
 {
     const int slot = blockIdx.y;
@@ -3067,6 +3076,58 @@ __global__ __launch_bounds__(256) void viterbi_fs_tri_kernel(const ViterbiArgs a
     viterbi_tri_update(gb, hb, qb, tb, p, lp1, a.PIP, k, nqb, ntb, pob);
     pp[n] = nqa; t2[n] = nta; pout[n] = poa;
     if (two) { pp[m] = nqb; t2[m] = ntb; pout[m] = pob; }
+}
+
+// The same update with the frame's log-posterior row and the slot's node scores staged in LDS.  Every triphone gathers four 4-B values (p[node],
+// lp[col0..2]) from two small arrays (9 KB + 7.6 KB at the real size); as global loads these are 8 wave-instructions per thread pair whose 64
+// lanes touch ~60 different cache lines each -- the L1's address path, not HBM, bounded the launch (269 us per frame at 192 active utterances
+// for 746 MB of state: 3 TB/s).  A block of 256 threads stages both arrays once (coalesced) and updates 512 * IT triphones from them.
+// (two slots per block, the constants shared between them: 66.7 against 59.1 ms per pass -- as above)
+template <int IT>
+__global__ __launch_bounds__(256) void viterbi_fs_tri_lds_kernel(const ViterbiArgs a, int k)
+{
+    extern __shared__ float vsm[];                          // [ldl] log-posteriors of frame k, [B] node scores
+    const int slot = blockIdx.y, T = a.T, B = a.B, L = (int)a.ldl;
+    const long long row0 = a.offsets[a.slot_utt[slot]];
+    const float* lp1 = a.lp + (size_t)(row0 + k) * a.ldl;
+    const float* p = a.p + (size_t)slot * B;
+    i32x4* pp = (i32x4*)a.pp + (size_t)slot * T;
+    int* t2 = a.tt + (size_t)slot * T;
+    float* pout = a.pout + (size_t)slot * T;
+    const i32x4* c0 = (const i32x4*)a.tri_idx;
+    const f32x4* c1 = (const f32x4*)a.tri_self;
+    const int base = blockIdx.x * IT * 512 + threadIdx.x;
+    // this thread's state and constants first (independent of the staging), then the staging loads: everything is in flight together
+    i32x4 ga[IT], gb[IT], qa[IT], qb[IT]; f32x4 ha[IT], hb[IT]; int ta[IT], tb[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int n0 = base + it * 512;
+        const int n = n0 < T ? n0 : T - 1, m = n0 + 256 < T ? n0 + 256 : T - 1;   // (past the end: repeats the last triphone's loads, stores nothing)
+        ga[it] = c0[n]; gb[it] = c0[m]; ha[it] = c1[n]; hb[it] = c1[m];
+        qa[it] = pp[n]; qb[it] = pp[m]; ta[it] = t2[n]; tb[it] = t2[m];
+    }
+    for (int i = threadIdx.x; i < L; i += 256) vsm[i] = lp1[i];
+    for (int i = threadIdx.x; i < B; i += 256) vsm[L + i] = p[i];
+    __syncthreads();
+    const float* s_lp = vsm;
+    const float* s_p = vsm + L;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int n = base + it * 512;
+        if (n >= T) break;
+        const bool two = n + 256 < T;
+        i32x4 nqa, nqb; int nta, ntb; float poa, pob;
+        {
+            const i32x4 g = ga[it];
+            viterbi_tri_apply(g, ha[it], qa[it], ta[it], s_p[g[0] & 0xffff], s_lp[(unsigned)g[0] >> 16], s_lp[g[1] & 0xffff], s_lp[(unsigned)g[1] >> 16], a.PIP, k, nqa, nta, poa);
+        }
+        {
+            const i32x4 g = gb[it];
+            viterbi_tri_apply(g, hb[it], qb[it], tb[it], s_p[g[0] & 0xffff], s_lp[(unsigned)g[0] >> 16], s_lp[g[1] & 0xffff], s_lp[(unsigned)g[1] >> 16], a.PIP, k, nqb, ntb, pob);
+        }
+        pp[n] = nqa; t2[n] = nta; pout[n] = poa;
+        if (two) { pp[n + 256] = nqb; t2[n + 256] = ntb; pout[n + 256] = pob; }
+    }
 }
 
 // 8 lanes per node (8 nodes per wave, 32 per block): a lane takes arrivals s0 + l, s0 + l + 8, ...; the first 8 trips are
@@ -3156,7 +3217,16 @@ hipError_t launch_viterbi_fs_init(hipStream_t s, const ViterbiArgs& a, int n_utt
 hipError_t launch_viterbi_fs_step(hipStream_t s, const ViterbiArgs& a, int k, int n_active)
 {
     if (n_active <= 0) return hipSuccess;
-    hipLaunchKernelGGL(viterbi_fs_tri_kernel, dim3((a.T + 511) / 512, n_active), dim3(256), 0, s, a, k);
+    const char* sv = getenv("AM_VITERBI_LDS");       // (measurement: 0 = every launch on the form that gathers from global memory)
+    const size_t lds = ((size_t)a.ldl + (size_t)a.B) * sizeof(float);
+    if ((!sv || atoi(sv) != 0) && lds <= 32 * 1024 && n_active >= 12) {
+        // trips per thread: 4 (2,048 triphones per staging) while that still gives several blocks per CU, 2 towards the tail of the run
+        const int trips = (a.T + 511) / 512;
+        if (n_active >= 24) hipLaunchKernelGGL(viterbi_fs_tri_lds_kernel<4>, dim3((trips + 3) / 4, n_active), dim3(256), lds, s, a, k);
+        else hipLaunchKernelGGL(viterbi_fs_tri_lds_kernel<2>, dim3((trips + 1) / 2, n_active), dim3(256), lds, s, a, k);
+    } else {
+        hipLaunchKernelGGL(viterbi_fs_tri_kernel, dim3((a.T + 511) / 512, n_active), dim3(256), 0, s, a, k);
+    }
     hipLaunchKernelGGL(viterbi_fs_node_kernel, dim3((a.B + 31) / 32, n_active), dim3(256), 0, s, a, k);
     return hipGetLastError();
 }

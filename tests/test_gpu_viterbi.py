@@ -86,6 +86,35 @@ def test_larger_graphs_match_oracle(engine, P, S, PIP):
     dec.close()
 
 
+@pytest.mark.parametrize("P,S", [(12, 300), (48, 1909)])
+def test_frame_sync_lds_form_matches_the_other_forms(engine, P, S, monkeypatch):
+    """With 12 or more active utterances the frame-synchronous triphone kernel stages the frame's log-posterior row and the node
+    scores in LDS (24 or more: 2,048 triphones per staging, else 1,024); below, and with AM_VITERBI_LDS=0, it gathers from
+    global memory.  40 utterances of 3..90 frames walk through all three; every form must give the oracle's segmentations
+    (small graph) / the per-utterance kernel's (real-size graph: the oracle on a sample)."""
+    from nnacousticmodeling_amd.phone_recog import PhoneRecog
+    rng = np.random.default_rng(P * 7 + S)
+    graph = vo.make_graph(rng, P, S)
+    lens = [int(v) for v in rng.integers(3, 91, size=40)]
+    lps = [_logsoftmax(4.0 * rng.standard_normal((n, S))).astype(np.float32) for n in lens]
+    offsets = np.concatenate([[0], np.cumsum(lens)])
+    lp = np.concatenate(lps)
+    dec = PhoneRecog(engine, dict(graph, numPhones=P, numBiphones=len(graph["lm"]), numTriphones=len(graph["biphoneIdxIn"])), -6.0, 0.8)
+    dec.set_form("frame_sync")
+    monkeypatch.setenv("AM_VITERBI_LDS", "1")
+    staged = dec.recognise(lp, offsets)
+    monkeypatch.setenv("AM_VITERBI_LDS", "0")
+    gathered = dec.recognise(lp, offsets)
+    dec.set_form("per_utt_compact")
+    per_utt = dec.recognise(lp, offsets)
+    assert staged == gathered == per_utt
+    assert sum(len(r) for r in staged) > 40
+    for u in (range(40) if P == 12 else (0, 17, 39)):
+        want = [(b, e, graph["phones"][t]) for b, e, t in vo.recog_one(graph, lps[u], -6.0, 0.8)]
+        assert staged[u] == want, u
+    dec.close()
+
+
 def test_arrival_lists_that_are_not_a_permutation(engine):
     """The decoder stores its state in arrival-list order when every triphone arrives at exactly one node; a graph where one
     triphone arrives nowhere and another at two nodes must take the general (gather) form and still match the oracle."""
