@@ -2220,13 +2220,13 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return offsets[x + 1] - offsets[x] > offsets[y + 1] - offsets[y]; });
         AM_TRY(upload_raw(e, d->d_slot, order.data(), order.size()));
         a.slot_utt = d->d_slot.as<int>();
-        const bool as_graph = env_int("AM_VITERBI_GRAPH", 0) != 0 && !e->profile;   // experiment: the launch sequence as one graph launch
-        if (as_graph) HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+        // (the launch sequence replayed as ONE hipGraph launch takes the same device time -- 78.7 ms both ways on the round-2 kernels: the host
+        // enqueues the ~1,280 launches in 3 ms, the boundaries are not the cost)
         int rc = run_kernel(e, K_VITERBI, [&] { return launch_viterbi_fs_init(e->stream, a, n_utts); });
         int active = n_utts;
         std::vector<hipEvent_t> seg_ev;                       // diagnostic (AM_VITERBI_TIMING=2): device time per 64 frames
         std::vector<int> seg_active;
-        const bool seg_timing = env_int("AM_VITERBI_TIMING", 0) == 2 && !as_graph;
+        const bool seg_timing = env_int("AM_VITERBI_TIMING", 0) == 2;
         for (int64_t k = 0; k < longest && rc == AM_OK; ++k) {
             while (active > 0 && offsets[order[active - 1] + 1] - offsets[order[active - 1]] <= k) --active;
             if (seg_timing && k % 64 == 0) { hipEvent_t ev; HIP_TRY(hipEventCreate(&ev)); HIP_TRY(hipEventRecord(ev, e->stream)); seg_ev.push_back(ev); seg_active.push_back(active); }
@@ -2243,19 +2243,6 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
             for (hipEvent_t ev2 : seg_ev) (void)hipEventDestroy(ev2);
         }
         if (rc == AM_OK) rc = run_kernel(e, K_VITERBI, [&] { return launch_viterbi_fs_trace(e->stream, a, n_utts); });
-        if (as_graph) {
-            hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
-            const hipError_t ce = hipStreamEndCapture(e->stream, &g);
-            if (rc == AM_OK && ce != hipSuccess) rc = fail(AM_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
-            if (rc == AM_OK && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) rc = fail(AM_EHIP, "hipGraphInstantiate failed");
-            if (rc == AM_OK) {
-                HIP_TRY(hipEventRecord(e->ev[62], e->stream));   // (the capture and instantiation are host time; the device time is the replay's)
-                if (hipGraphLaunch(ge, e->stream) != hipSuccess) rc = fail(AM_EHIP, "hipGraphLaunch failed");
-                HIP_TRY(hipStreamSynchronize(e->stream));
-            }
-            if (ge) (void)hipGraphExecDestroy(ge);
-            if (g) (void)hipGraphDestroy(g);
-        }
         AM_TRY(rc);
     } else
     AM_TRY(run_kernel(e, K_VITERBI, [&] { return launch_viterbi(e->stream, a, n_utts); }));
