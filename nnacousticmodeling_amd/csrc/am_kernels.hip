@@ -1898,10 +1898,22 @@ __device__ __forceinline__ bool persist_step_wide(const LstmPersistArgs& a, cons
     const bool t1_here = have < 2;
     if (t1_here) dma_tile(uprs, up0 + TB, smem + OFF1);
     persist_stamp(a, gidx, ut, t, 1);
-    const int erow = tid >> 2, quad = tid & 3;
-    const bool live = erow < ROWS && erow < rows_valid;
-    f32x4 cq = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    // epilogue thread = (row, 4 units) with three or four row tiles (16-B loads and stores); with one or two, (row, ONE unit): 256 / 512 threads share
+    // the gate arithmetic instead of 64 / 128 -- the gate phase is VALU time with the matrix pipe idle (0.65 -> 0.42 us, the publish behind it
+    // 0.74 -> 0.35).  Two units per thread at three or four row tiles, all eight waves storing 8 B per lane, was measured too: gate phase unchanged,
+    // the drain of the write-through stores 0.49 -> 1.2 us.
+    // (all derived from an opaque copy of the thread index at each use: neither they nor the byte offsets built from them are held through the MFMA phases)
+    auto tid_now = [&] { int x = tid; asm volatile("" : "+v"(x)); return x; };
+    auto row_of = [&](int x) { return THIN ? x >> 4 : x >> 2; };
+    auto is_live = [&](int er) { return er < ROWS && er < rows_valid; };
+    f32x4 cq = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};   // (thin: cq[0] only)
     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void*)Ly.Cst, 0, 0x7fffffff, 0x00020000);
+    auto load_c = [&] {   // the previous cell state of this thread's unit(s)
+        const int x = tid_now(), er = row_of(x);
+        if (!is_live(er)) return;
+        if (THIN) cq[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(crs, (int)(((r_p + er) * (unsigned)U_pad + (unsigned)(ut * 16 + (x & 15))) * 4u), 0, 16 /* sc1 */));
+        else cq = ld_sc1_b128(crs, ((r_p + er) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * (x & 3))) * 4u);
+    };
     f32x4 acc[NT];
 #pragma unroll
     for (int r = 0; r < NT; ++r) acc[r] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
@@ -1934,7 +1946,7 @@ __device__ __forceinline__ bool persist_step_wide(const LstmPersistArgs& a, cons
             if (tid < 64) { seenL = pk[lane]; tgtL = pk[64 + lane]; }
             if (!persist_wait_seen(a, Ly.group0, Ly.n_groups, seenL, tgtL, s_flag)) return false;
             // few rows: registers to spare and short batches -- the previous cell state is requested here (many rows: under the last tile's MFMAs)
-            if (THIN && live) cq = ld_sc1_b128(crs, ((r_p + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u);
+            if (THIN) load_c();
             if (want_next) peek(Lb.group0, Lb.n_groups, t + 1, pk + 128);   // (both before the tiles: b == 2's counted wait must cover them)
             if (THIN) { dma_tile(hrs, lat0, smem + OFF2); dma_tile(hrs, lat0 + TB, smem + OFF3); }   // few rows: the step is a chain of latencies, both lateral tiles leave at once
         } else {
@@ -1944,7 +1956,7 @@ __device__ __forceinline__ bool persist_step_wide(const LstmPersistArgs& a, cons
             }
             __builtin_amdgcn_s_barrier();
             if (b == 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); pre = __builtin_amdgcn_readfirstlane(s_flag[1]); }
-            if (!THIN && b == 3 && live) cq = ld_sc1_b128(crs, ((r_p + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u);
+            if (!THIN && b == 3) load_c();
         }
         if (b == 2) persist_stamp(a, gidx, ut, t, 2);
         const bool due = !THIN && lat && (b == 1 || b == 2);       // the buffer of tile b + 1 is free: everybody is past tile b - 1
@@ -2016,6 +2028,31 @@ __device__ __forceinline__ bool persist_step_wide(const LstmPersistArgs& a, cons
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
             sg[((kh * 4 + gate) * ROWS + r * 16 + lq * 4 + reg) * PERSIST_SGLD + l15] = acc[r][reg];
+    const int etid = tid_now(), erow = row_of(etid), quad = etid & 3, eu = etid & 15;
+    const bool live = is_live(erow);
+    if constexpr (THIN) {
+        float g1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g1[k] = live ? Ly.bias[ut * 64 + k * 16 + eu] : 0.0f;
+        __syncthreads();
+        if (live) {
+            float pre[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                pre[k] = (sg[((0 * 4 + k) * ROWS + erow) * PERSIST_SGLD + eu] + sg[((1 * 4 + k) * ROWS + erow) * PERSIST_SGLD + eu]) + g1[k];
+            const float ga = am_tanh_rec(pre[0]);
+            const float gi = am_sigmoid_rec(pre[1]);
+            const float gf = am_sigmoid_rec(pre[2]);
+            const float go = am_sigmoid_rec(pre[3]);
+            const float ai = ga * gi;
+            const float fc = gf * cq[0];
+            const float c = ai + fc;
+            const float h = go * am_tanh_rec(c);
+            const unsigned off = ((r_t + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + eu)) * 4u;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c), crs, (int)off, 0, 16 /* sc1 */);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h), hrs, (int)off, 0, 16 /* sc1 */);
+        }
+    } else {
     f32x4 gq[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -2043,6 +2080,7 @@ __device__ __forceinline__ bool persist_step_wide(const LstmPersistArgs& a, cons
         }
         st_sc1_b128(crs, ((r_t + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u, cn);
         st_sc1_b128(hrs, ((r_t + erow) * (unsigned)U_pad + (unsigned)(ut * 16 + 4 * quad)) * 4u, hn);
+    }
     }
     persist_stamp(a, gidx, ut, t, 5);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
