@@ -206,6 +206,22 @@ def gemm_roofline(prof, flops_total):
     return calls, ms, achieved
 
 
+class _Guarded:
+    """A secondary record that fails must not take the bench line (and the records behind it) down with it: the failure is recorded in its place."""
+
+    def __init__(self, out, name):
+        self.out, self.name = out, name
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, etype, exc, tb):
+        if etype is not None and issubclass(etype, Exception):
+            self.out[self.name] = {"error": "%s: %s" % (etype.__name__, exc)}
+            return True
+        return False
+
+
 def secondary_records(eng, ft, params, layers, x, steps):
     """The other BASELINE.json configurations and SURVEY.md 8d figures, one GPU, outside the headline `value`:
     end to end (host array in, pinned host array out), the core-test-like size, 6x2048 + i-vectors, the 3x512 LSTM, the 10-member ensemble."""
@@ -216,176 +232,185 @@ def secondary_records(eng, ft, params, layers, x, steps):
     golden = os.path.join(ROOT, "tests", "golden")
     n_full = x.shape[0]
     m4 = Model(eng, "ff", layers, params)
-    # (i) end to end: H2D of the frames, compute, D2H of the posteriors into page-locked memory (PCIe-inclusive; never `value`)
-    p = Pipeline(eng)
-    p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
-    p.set_members([m4])
-    y = eng.pinned_empty((n_full, 1909))
-    p.forward_ff(x, out=y)
-    t0 = time.perf_counter()
-    reps = 3
-    for _ in range(reps):
-        p.forward_ff(x, out=y)
-    dt = (time.perf_counter() - t0) / reps
-    out["end_to_end"] = {"value": n_full / dt, "unit": "frames/s", "ms_per_pass": dt * 1e3, "frames": n_full,
-                         "what": "host array -> H2D -> splice+transform+4x1024+log-softmax -> D2H into page-locked host memory "
-                                 "(7.6 KB of posteriors per frame over PCIe; download of chunk c overlaps compute of chunk c+1)"}
-    del y
-    # (ii) the same network at the TIMIT core-test size (57,919 frames = 226.2 row tiles: partial last round of tiles)
     n57 = 57919
-    p.ff_upload(x[:n57], None, n57, 0, 0)
-    wall, _, prof = timed_runs(eng, p.ff_run, max(steps, 5), 2, pipe=p)
-    k = max(steps, 5)
-    whole = FLOPS_PER_FRAME["4x1024"] * n57 * k / wall / 1e12
-    out["n57919"] = {"value": n57 * k / wall, "unit": "frames/s", "ms_per_step": wall * 1e3 / k, "frames": n57,
-                     "roofline": {"bound": "mfma", "kernel": "whole step (splice + transform, the Linear stack, log-softmax): the fraction is flop / wall time / peak",
-                                  "achieved": whole, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": whole / PEAK_F32_MFMA_TFLOPS},
-                     "gemm_launch_ms_sum_per_step": sum(prof[k_][1] for k_ in ("gemm_hidden", "gemm_out", "gemm_stack") if k_ in prof) / k}
-    _, gms, gach = gemm_roofline(prof, FLOPS_PER_FRAME["4x1024"] * n57 * k)
-    out["n57919"]["roofline_gemm"] = {"bound": "mfma", "kernel": "the Linear layers' launches alone (gemm_stack_kernel: one launch per step), as for the headline record",
-                                      "achieved": gach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": gach / PEAK_F32_MFMA_TFLOPS if gach else None}
-    p.close()
-    m4.close()
-    # (iii) BASELINE configs[2]: 6x2048 on 440 spliced + 100 i-vector columns
-    rng = np.random.default_rng(SEED + 2)
-    p6 = make_mlp_params(rng, 540, 2048, 6, 1909)
-    iv = rng.standard_normal((n_full, 100)).astype(np.float32)
-    m6 = Model(eng, "ff", 6, p6)
-    p = Pipeline(eng)
-    p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"], 100)
-    p.set_members([m6])
-    p.ff_upload(x, iv, n_full, 0, 0)
-    k6 = max(steps // 4, 3)
-    wall, _, prof = timed_runs(eng, p.ff_run, k6, 1, pipe=p)
-    _, _, ach = gemm_roofline(prof, FLOPS_PER_FRAME["6x2048"] * n_full * k6)
-    out["dnn_6x2048_ivec"] = {"value": n_full * k6 / wall, "unit": "frames/s", "ms_per_step": wall * 1e3 / k6, "frames": n_full,
-                              "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS if ach else None}}
-    p.close()
-    m6.close()
-    del iv
-    # (iv) BASELINE configs[3]: 3x512 LSTM (uni-directional: the reference has no bidirectional net, SURVEY.md M1), 192 utterances
     ftc = select_centre_frame(loadKaldiFeatureTransform(os.path.join(golden, "final.feature_transform")))
-    rng = np.random.default_rng(SEED + 3)
-    off = make_offsets(rng, 192, n57)
-    ml = Model(eng, "lstm", 3, make_lstm_params(rng, 40, 512, 3, 1909))
-    p = Pipeline(eng)
-    p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
-    p.set_members([ml])
-    p.lstm_upload(x[:n57], None, off, 0)
-    kl = max(steps // 2, 5)
-    wall, _, prof = timed_runs(eng, p.lstm_run, kl, 3, pipe=p)
-    fl = 2 * (40 * 2048 + 2 * 512 * 2048 + 3 * 512 * 2048 + 512 * 1909)
-    rec_ms = prof.get("lstm_step", (0, 0.0))[1] / kl
-    rec_flops = 2 * (2 * 512 * 2048 + 3 * 512 * 2048) * n57       # the recurrent kernel's share: lateral x3 + upward x2
-    out["lstm_3x512"] = {"value": n57 * kl / wall, "unit": "frames/s", "ms_per_pass": wall * 1e3 / kl, "frames": n57, "utterances": 192,
-                         "longest_utterance": int(np.diff(off).max()),
-                         "roofline": {"bound": "mfma (dependent time steps: latency-bound below ~64 active utterances)", "kernel": "whole pass",
-                                      "achieved": fl * n57 * kl / wall / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                      "frac": fl * n57 * kl / wall / 1e12 / PEAK_F32_MFMA_TFLOPS},
-                         "recurrent_kernel": {"ms_per_pass": rec_ms, "launches_per_pass": prof.get("lstm_step", (0, 0.0))[0] // kl,
-                                              "achieved_tflops": rec_flops / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else None},
-                         "kernels_ms_per_pass": {k_: v[1] / kl for k_, v in prof.items()}}
-    p.close()
-    ml.close()
+    off = make_offsets(np.random.default_rng(SEED + 3), 192, n57)   # 192 utterances of the core-test-like file (recurrent and decoder records)
+    from nnacousticmodeling_amd.synthetic import make_gru_params, make_tdnn_params
+    # (i) end to end: H2D of the frames, compute, D2H of the posteriors into page-locked memory (PCIe-inclusive; never `value`)
+    with _Guarded(out, "end_to_end"):
+        p = Pipeline(eng)
+        p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+        p.set_members([m4])
+        y = eng.pinned_empty((n_full, 1909))
+        p.forward_ff(x, out=y)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            p.forward_ff(x, out=y)
+        dt = (time.perf_counter() - t0) / reps
+        out["end_to_end"] = {"value": n_full / dt, "unit": "frames/s", "ms_per_pass": dt * 1e3, "frames": n_full,
+                             "what": "host array -> H2D -> splice+transform+4x1024+log-softmax -> D2H into page-locked host memory "
+                                     "(7.6 KB of posteriors per frame over PCIe; download of chunk c overlaps compute of chunk c+1)"}
+        del y
+    # (ii) the same network at the TIMIT core-test size (57,919 frames = 226.2 row tiles: partial last round of tiles)
+    with _Guarded(out, "n57919"):
+        p.ff_upload(x[:n57], None, n57, 0, 0)
+        wall, _, prof = timed_runs(eng, p.ff_run, max(steps, 5), 2, pipe=p)
+        k = max(steps, 5)
+        whole = FLOPS_PER_FRAME["4x1024"] * n57 * k / wall / 1e12
+        out["n57919"] = {"value": n57 * k / wall, "unit": "frames/s", "ms_per_step": wall * 1e3 / k, "frames": n57,
+                         "roofline": {"bound": "mfma", "kernel": "whole step (splice + transform, the Linear stack, log-softmax): the fraction is flop / wall time / peak",
+                                      "achieved": whole, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": whole / PEAK_F32_MFMA_TFLOPS},
+                         "gemm_launch_ms_sum_per_step": sum(prof[k_][1] for k_ in ("gemm_hidden", "gemm_out", "gemm_stack") if k_ in prof) / k}
+        _, gms, gach = gemm_roofline(prof, FLOPS_PER_FRAME["4x1024"] * n57 * k)
+        out["n57919"]["roofline_gemm"] = {"bound": "mfma", "kernel": "the Linear layers' launches alone (gemm_stack_kernel: one launch per step), as for the headline record",
+                                          "achieved": gach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": gach / PEAK_F32_MFMA_TFLOPS if gach else None}
+        p.close()
+        m4.close()
+    # (iii) BASELINE configs[2]: 6x2048 on 440 spliced + 100 i-vector columns
+    with _Guarded(out, "dnn_6x2048_ivec"):
+        rng = np.random.default_rng(SEED + 2)
+        p6 = make_mlp_params(rng, 540, 2048, 6, 1909)
+        iv = rng.standard_normal((n_full, 100)).astype(np.float32)
+        m6 = Model(eng, "ff", 6, p6)
+        p = Pipeline(eng)
+        p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"], 100)
+        p.set_members([m6])
+        p.ff_upload(x, iv, n_full, 0, 0)
+        k6 = max(steps // 4, 3)
+        wall, _, prof = timed_runs(eng, p.ff_run, k6, 1, pipe=p)
+        _, _, ach = gemm_roofline(prof, FLOPS_PER_FRAME["6x2048"] * n_full * k6)
+        out["dnn_6x2048_ivec"] = {"value": n_full * k6 / wall, "unit": "frames/s", "ms_per_step": wall * 1e3 / k6, "frames": n_full,
+                                  "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS if ach else None}}
+        p.close()
+        m6.close()
+        del iv
+    # (iv) BASELINE configs[3]: 3x512 LSTM (uni-directional: the reference has no bidirectional net, SURVEY.md M1), 192 utterances
+    with _Guarded(out, "lstm_3x512"):
+        rng = np.random.default_rng(SEED + 3)
+        make_offsets(rng, 192, n57)   # (advances rng exactly as before: the same weights as earlier rounds)
+        ml = Model(eng, "lstm", 3, make_lstm_params(rng, 40, 512, 3, 1909))
+        p = Pipeline(eng)
+        p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
+        p.set_members([ml])
+        p.lstm_upload(x[:n57], None, off, 0)
+        kl = max(steps // 2, 5)
+        wall, _, prof = timed_runs(eng, p.lstm_run, kl, 3, pipe=p)
+        fl = 2 * (40 * 2048 + 2 * 512 * 2048 + 3 * 512 * 2048 + 512 * 1909)
+        rec_ms = prof.get("lstm_step", (0, 0.0))[1] / kl
+        rec_flops = 2 * (2 * 512 * 2048 + 3 * 512 * 2048) * n57       # the recurrent kernel's share: lateral x3 + upward x2
+        out["lstm_3x512"] = {"value": n57 * kl / wall, "unit": "frames/s", "ms_per_pass": wall * 1e3 / kl, "frames": n57, "utterances": 192,
+                             "longest_utterance": int(np.diff(off).max()),
+                             "roofline": {"bound": "mfma (dependent time steps: latency-bound below ~64 active utterances)", "kernel": "whole pass",
+                                          "achieved": fl * n57 * kl / wall / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": fl * n57 * kl / wall / 1e12 / PEAK_F32_MFMA_TFLOPS},
+                             "recurrent_kernel": {"ms_per_pass": rec_ms, "launches_per_pass": prof.get("lstm_step", (0, 0.0))[0] // kl,
+                                                  "achieved_tflops": rec_flops / (rec_ms * 1e-3) / 1e12 if rec_ms > 0 else None},
+                             "kernels_ms_per_pass": {k_: v[1] / kl for k_, v in prof.items()}}
+        p.close()
+        ml.close()
     # (v) BASELINE configs[4]: 10 fold members (4x1024 each), logits averaged on the device (evaluate.py:35-51) -- one GPU's share;
     # on a node the folds x utterances shard over the GPUs with no collective (sharding.py)
-    rng = np.random.default_rng(SEED + 4)
-    members = [Model(eng, "ff", layers, make_mlp_params(rng, 440, 1024, layers, 1909)) for _ in range(10)]
-    p = Pipeline(eng)
-    p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
-    p.set_members(members)
-    p.ff_upload(x[:n57], None, n57, 0, 0)
-    ke = max(steps // 6, 3)
-    wall, _, prof = timed_runs(eng, p.ff_run, ke, 1, pipe=p)
-    whole = 10 * FLOPS_PER_FRAME["4x1024"] * n57 * ke / wall / 1e12
-    _, _, gach = gemm_roofline(prof, 10 * FLOPS_PER_FRAME["4x1024"] * n57 * ke)
-    out["ensemble_10x4x1024"] = {"value": n57 * ke / wall, "unit": "frames/s", "ms_per_pass": wall * 1e3 / ke, "frames": n57, "members": 10,
-                                 "roofline": {"bound": "mfma", "kernel": "whole pass (10 stack launches + combine + log-softmax)", "achieved": whole,
-                                              "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": whole / PEAK_F32_MFMA_TFLOPS},
-                                 "roofline_gemm": {"bound": "mfma", "achieved": gach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                                   "frac": gach / PEAK_F32_MFMA_TFLOPS if gach else None}}
-    p.close()
-    for m_ in members:
-        m_.close()
+    with _Guarded(out, "ensemble_10x4x1024"):
+        rng = np.random.default_rng(SEED + 4)
+        members = [Model(eng, "ff", layers, make_mlp_params(rng, 440, 1024, layers, 1909)) for _ in range(10)]
+        p = Pipeline(eng)
+        p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+        p.set_members(members)
+        p.ff_upload(x[:n57], None, n57, 0, 0)
+        ke = max(steps // 6, 3)
+        wall, _, prof = timed_runs(eng, p.ff_run, ke, 1, pipe=p)
+        whole = 10 * FLOPS_PER_FRAME["4x1024"] * n57 * ke / wall / 1e12
+        _, _, gach = gemm_roofline(prof, 10 * FLOPS_PER_FRAME["4x1024"] * n57 * ke)
+        out["ensemble_10x4x1024"] = {"value": n57 * ke / wall, "unit": "frames/s", "ms_per_pass": wall * 1e3 / ke, "frames": n57, "members": 10,
+                                     "roofline": {"bound": "mfma", "kernel": "whole pass (10 stack launches + combine + log-softmax)", "achieved": whole,
+                                                  "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": whole / PEAK_F32_MFMA_TFLOPS},
+                                     "roofline_gemm": {"bound": "mfma", "achieved": gach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                                       "frac": gach / PEAK_F32_MFMA_TFLOPS if gach else None}}
+        p.close()
+        for m_ in members:
+            m_.close()
     # (vi) row n4: the GRU stack at the recurrent config's size (chainer L.GRU: two dependent products per step)
-    rng = np.random.default_rng(SEED + 5)
-    from nnacousticmodeling_amd.synthetic import make_gru_params, make_tdnn_params
-    mg = Model(eng, "gru", 3, make_gru_params(rng, 40, 512, 3, 1909, reset_gate=True))
-    p = Pipeline(eng)
-    p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
-    p.set_members([mg])
-    p.lstm_upload(x[:n57], None, off, 0)
-    kg = max(steps // 4, 3)
-    wall, _, prof = timed_runs(eng, p.lstm_run, kg, 2, pipe=p)
-    fl = 2 * (3 * (40 * 512 + 2 * 512 * 512 + 3 * 512 * 512) + 512 * 1909)
-    out["gru_3x512"] = {"value": n57 * kg / wall, "unit": "frames/s", "ms_per_pass": wall * 1e3 / kg, "frames": n57, "utterances": 192,
-                        "roofline": {"bound": "mfma (dependent time steps)", "kernel": "whole pass", "achieved": fl * n57 * kg / wall / 1e12,
-                                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": fl * n57 * kg / wall / 1e12 / PEAK_F32_MFMA_TFLOPS},
-                        "recurrent_form": "%d of %d members as one persistent launch" % p.recurrent_form(),
-                        "kernels_ms_per_pass": {k_: v[1] / kg for k_, v in prof.items()}, "launches_per_pass": {k_: v[0] // kg for k_, v in prof.items()}}
-    p.close()
-    mg.close()
+    with _Guarded(out, "gru_3x512"):
+        rng = np.random.default_rng(SEED + 5)
+        mg = Model(eng, "gru", 3, make_gru_params(rng, 40, 512, 3, 1909, reset_gate=True))
+        p = Pipeline(eng)
+        p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
+        p.set_members([mg])
+        p.lstm_upload(x[:n57], None, off, 0)
+        kg = max(steps // 4, 3)
+        wall, _, prof = timed_runs(eng, p.lstm_run, kg, 2, pipe=p)
+        fl = 2 * (3 * (40 * 512 + 2 * 512 * 512 + 3 * 512 * 512) + 512 * 1909)
+        out["gru_3x512"] = {"value": n57 * kg / wall, "unit": "frames/s", "ms_per_pass": wall * 1e3 / kg, "frames": n57, "utterances": 192,
+                            "roofline": {"bound": "mfma (dependent time steps)", "kernel": "whole pass", "achieved": fl * n57 * kg / wall / 1e12,
+                                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": fl * n57 * kg / wall / 1e12 / PEAK_F32_MFMA_TFLOPS},
+                            "recurrent_form": "%d of %d members as one persistent launch" % p.recurrent_form(),
+                            "kernels_ms_per_pass": {k_: v[1] / kg for k_, v in prof.items()}, "launches_per_pass": {k_: v[0] // kg for k_, v in prof.items()}}
+        p.close()
+        mg.close()
     # (vii) row n4: TDNN 5-5-5-5 x 1024 (scripts/papers/tsd2018/run.sh:22-30): every (1, k) convolution as one MFMA GEMM with windowed rows
-    from nnacousticmodeling_amd.kaldi_ft import tdnn_splice, tile_centre_frame
-    ksize, units = [5, 5, 5, 5], [1024] * 4
-    tft = tile_centre_frame(loadKaldiFeatureTransform(os.path.join(golden, "final.feature_transform")), tdnn_splice(ksize))
-    mt = Model(eng, "tdnn", 4, make_tdnn_params(rng, 40, units, ksize, 1909))
-    p = Pipeline(eng)
-    p.set_frontend(40, tft["shifts"], tft["addShift"], tft["rescale"])
-    p.set_members([mt])
-    p.ff_upload(x[:n57], None, n57, 0, 0)
-    kt = 3
-    wall, _, prof = timed_runs(eng, p.ff_run, kt, 1, pipe=p)
-    pos, cin, fl = sum(ksize) - 3, 40, 0
-    for u_, k_ in zip(units, ksize):
-        pos -= k_ - 1
-        fl += 2 * pos * cin * k_ * u_
-        cin = u_
-    fl += 2 * cin * 1909
-    _, _, gach = gemm_roofline(prof, fl * n57 * kt)
-    out["tdnn_5555x1024"] = {"value": n57 * kt / wall, "unit": "frames/s", "ms_per_pass": wall * 1e3 / kt, "frames": n57, "flop_per_frame": fl,
-                             "roofline": {"bound": "mfma", "kernel": "the convolution / output GEMM launches", "achieved": gach, "peak": PEAK_F32_MFMA_TFLOPS,
-                                          "unit": "TFLOP/s", "frac": gach / PEAK_F32_MFMA_TFLOPS if gach else None}}
-    p.close()
-    mt.close()
+    with _Guarded(out, "tdnn_5555x1024"):
+        from nnacousticmodeling_amd.kaldi_ft import tdnn_splice, tile_centre_frame
+        ksize, units = [5, 5, 5, 5], [1024] * 4
+        tft = tile_centre_frame(loadKaldiFeatureTransform(os.path.join(golden, "final.feature_transform")), tdnn_splice(ksize))
+        mt = Model(eng, "tdnn", 4, make_tdnn_params(rng, 40, units, ksize, 1909))
+        p = Pipeline(eng)
+        p.set_frontend(40, tft["shifts"], tft["addShift"], tft["rescale"])
+        p.set_members([mt])
+        p.ff_upload(x[:n57], None, n57, 0, 0)
+        kt = 3
+        wall, _, prof = timed_runs(eng, p.ff_run, kt, 1, pipe=p)
+        pos, cin, fl = sum(ksize) - 3, 40, 0
+        for u_, k_ in zip(units, ksize):
+            pos -= k_ - 1
+            fl += 2 * pos * cin * k_ * u_
+            cin = u_
+        fl += 2 * cin * 1909
+        _, _, gach = gemm_roofline(prof, fl * n57 * kt)
+        out["tdnn_5555x1024"] = {"value": n57 * kt / wall, "unit": "frames/s", "ms_per_pass": wall * 1e3 / kt, "frames": n57, "flop_per_frame": fl,
+                                 "roofline": {"bound": "mfma", "kernel": "the convolution / output GEMM launches", "achieved": gach, "peak": PEAK_F32_MFMA_TFLOPS,
+                                              "unit": "TFLOP/s", "frac": gach / PEAK_F32_MFMA_TFLOPS if gach else None}}
+        p.close()
+        mt.close()
     # (viii) row n1: the frame-synchronous Viterbi decoder on a synthetic graph of the real image's size (48 phones, 2,304 nodes,
     # ~88k triphones, 1909 states; the inputs tests/golden/make_viterbi_fullsize_golden.py describes), 192 utterances / 57,919 frames
-    from nnacousticmodeling_amd.phone_recog import PhoneRecog
-    from nnacousticmodeling_amd.synthetic import make_graph
-    rng = np.random.default_rng(481909)
-    graph = make_graph(rng, 48, 1909)
-    T_, B_ = len(graph["biphoneIdxIn"]), len(graph["lm"])
-    z = rng.standard_normal((n57, 1909), dtype=np.float32)
-    z *= 2.0
-    mx = z.max(axis=1, keepdims=True)
-    z -= mx + np.log(np.exp(z - mx).sum(axis=1, keepdims=True))
-    dec = PhoneRecog(eng, dict(graph, numPhones=48, numBiphones=B_, numTriphones=T_), -20.0, 1.0)
-    dec.recognise(z[:off[4]], off[:5])
-    t0 = time.perf_counter()
-    res = dec.recognise(z, off)
-    host_s = time.perf_counter() - t0
-    pass_ms = eng.elapsed_ms(62, 63)   # device time of the un-instrumented pass: first launch -> last launch done (am_decode_* records both)
-    eng.profile(True)
-    eng.profile_reset()
-    dec.recognise(z, off)
-    vprof = eng.profile_read()
-    eng.profile(False)
-    vit_ms = pass_ms                   # the roofline figure: the whole pass as it runs in production, launch gaps included
-    steps_v = int(np.diff(off).max())
-    # HBM bytes the pass cannot avoid: per (utterance, frame) the state of every triphone read (20 B) and written (24 B), the node
-    # back-pointers (8 B) and the frame's posterior row; per frame-launch the graph constants once (32 B per triphone, shared by all
-    # utterances of the launch: L2 / Infinity Cache serve the repeats)
-    vit_bytes = n57 * (T_ * 44 + B_ * 8 + 1909 * 4) + steps_v * T_ * 32
-    out["viterbi_realsize"] = {"value": n57 / (vit_ms * 1e-3), "unit": "frames/s (device time of the pass)", "pass_ms": vit_ms,
-                               "kernel_ms_sum_with_an_event_pair_per_launch": vprof["viterbi"][1], "launches": vprof["viterbi"][0],
-                               "host_array_to_segments_s": host_s, "frames": n57, "utterances": 192, "segments": sum(len(r) for r in res),
-                               "graph": {"phones": 48, "nodes": B_, "triphones": T_, "states": 1909},
-                               "roofline": {"bound": "hbm", "kernel": "viterbi_fs_tri_kernel + viterbi_fs_node_kernel (one launch pair per frame over all active utterances)",
-                                            "achieved": vit_bytes / (vit_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": vit_bytes / (vit_ms * 1e-3) / 8e12,
-                                            "algorithmic_bytes": vit_bytes,
-                                            "measured": "one HIP event pair around the pass's launch sequence on the engine's compute stream"}}
-    dec.close()
-    del z
+    with _Guarded(out, "viterbi_realsize"):
+        from nnacousticmodeling_amd.phone_recog import PhoneRecog
+        from nnacousticmodeling_amd.synthetic import make_graph
+        rng = np.random.default_rng(481909)
+        graph = make_graph(rng, 48, 1909)
+        T_, B_ = len(graph["biphoneIdxIn"]), len(graph["lm"])
+        z = rng.standard_normal((n57, 1909), dtype=np.float32)
+        z *= 2.0
+        mx = z.max(axis=1, keepdims=True)
+        z -= mx + np.log(np.exp(z - mx).sum(axis=1, keepdims=True))
+        dec = PhoneRecog(eng, dict(graph, numPhones=48, numBiphones=B_, numTriphones=T_), -20.0, 1.0)
+        dec.recognise(z[:off[4]], off[:5])
+        t0 = time.perf_counter()
+        res = dec.recognise(z, off)
+        host_s = time.perf_counter() - t0
+        pass_ms = eng.elapsed_ms(62, 63)   # device time of the un-instrumented pass: first launch -> last launch done (am_decode_* records both)
+        eng.profile(True)
+        eng.profile_reset()
+        dec.recognise(z, off)
+        vprof = eng.profile_read()
+        eng.profile(False)
+        vit_ms = pass_ms                   # the roofline figure: the whole pass as it runs in production, launch gaps included
+        steps_v = int(np.diff(off).max())
+        # HBM bytes the pass cannot avoid: per (utterance, frame) the state of every triphone read (20 B) and written (24 B), the node
+        # back-pointers (8 B) and the frame's posterior row; per frame-launch the graph constants once (32 B per triphone, shared by all
+        # utterances of the launch: L2 / Infinity Cache serve the repeats)
+        vit_bytes = n57 * (T_ * 44 + B_ * 8 + 1909 * 4) + steps_v * T_ * 32
+        out["viterbi_realsize"] = {"value": n57 / (vit_ms * 1e-3), "unit": "frames/s (device time of the pass)", "pass_ms": vit_ms,
+                                   "kernel_ms_sum_with_an_event_pair_per_launch": vprof["viterbi"][1], "launches": vprof["viterbi"][0],
+                                   "host_array_to_segments_s": host_s, "frames": n57, "utterances": 192, "segments": sum(len(r) for r in res),
+                                   "graph": {"phones": 48, "nodes": B_, "triphones": T_, "states": 1909},
+                                   "roofline": {"bound": "hbm", "kernel": "viterbi_fs_tri_kernel + viterbi_fs_node_kernel (one launch pair per frame over all active utterances)",
+                                                "achieved": vit_bytes / (vit_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": vit_bytes / (vit_ms * 1e-3) / 8e12,
+                                                "algorithmic_bytes": vit_bytes,
+                                                "measured": "one HIP event pair around the pass's launch sequence on the engine's compute stream"}}
+        dec.close()
+        del z
     return out
 
 

@@ -114,6 +114,31 @@ def test_recurrent_forms_agree_bit_for_bit(engine, real_ft_path, monkeypatch):
         p.close()
 
 
+@pytest.mark.parametrize("layers,units", [(2, 512), (4, 512), (5, 512), (6, 256)])
+def test_reference_recipe_shapes_agree_across_recurrent_forms(engine, real_ft_path, monkeypatch, layers, units):
+    """The LSTM shapes the reference's recipes train (scripts/papers/tsd2018/run.sh:33-41: 2..6 layers x 256 / 512 units,
+    --timedelay 5): deeper stacks change the persistent kernel's plan -- fewer row groups per layer, more row tiles per group,
+    fewer utterance slots per launch (several chunks), other tile counts in the 256-k step form -- and every plan must give the
+    per-step kernels' bits; plus the oracle on a sample."""
+    ft = orc.centre_frame_transform(orc.load_kaldi_feature_transform(real_ft_path))
+    rng = np.random.default_rng(100 * layers + units)
+    params = orc.make_lstm_params(rng, 40, units, layers, 1909)
+    off = orc.make_offsets(rng, 150, 9000, lo=3, hi=140)
+    x = rng.standard_normal((9000, 40)).astype(np.float32)
+    p = _pipe(engine, "lstm", layers, params, ft, [0])
+    whole = p.forward_lstm(x, off, timedelay=5)
+    assert p.recurrent_form() == (1, 1)
+    monkeypatch.setenv("AM_LSTM_PERSIST", "0")
+    steps = p.forward_lstm(x, off, timedelay=5)
+    monkeypatch.delenv("AM_LSTM_PERSIST")
+    assert p.recurrent_form() == (0, 1)
+    assert np.array_equal(steps, whole)
+    k = 4
+    want = orc.predict(orc.LSTM(params, layers), x[:off[k]], off[:k + 1], True, 1, 5, ft)
+    assert np.max(np.abs(whole[:off[k]] - want)) <= TOL
+    p.close()
+
+
 @pytest.mark.expects_fallback
 def test_persistent_kernel_gives_up_and_falls_back(engine, real_ft_path, monkeypatch, capfd):
     """The persistent recurrent kernel's inter-workgroup waits are bounded (2 s).  With an arrival target nobody can reach
