@@ -168,9 +168,10 @@ struct am_pipeline {
     // persistent form of the LSTM stack (lstm_persist_kernel): per member the group plan + arrival table, shared step tables
     struct PersistPlan {
         int form = 0;                       // 0 per-step kernels, 1 lstm_persist_kernel
-        std::vector<LstmPersistArgs> chunks;   // one launch per chunk of utterance slots (utterances are independent; longest first)
+        std::vector<LstmPersistArgs> chunks;   // one launch per (layer segment, chunk of utterance slots); utterances are independent, longest first
+        std::vector<int> layer0;               // the model layer that is L[0] of chunks[i] (a deep stack runs as several launches over layer ranges)
         std::vector<DevBuf> cums;
-        void release() { for (auto& c : cums) c.release(); cums.clear(); chunks.clear(); form = 0; }
+        void release() { for (auto& c : cums) c.release(); cums.clear(); chunks.clear(); layer0.clear(); form = 0; }
     };
     std::vector<PersistPlan> persist;
     DevBuf d_nact, d_stepoff, d_sync;   // int [T], int [T + 1], unsigned [groups + 1] (arrival counters, abort flag last)
@@ -1558,22 +1559,51 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
             auto& pl = p->persist[mi];
             const int U_pad = m->L[0].U_pad;
             const int max_wgs = lstm_persist_resident_wgs(U_pad, e->n_cus);
-            const int cap = lstm_persist_capacity(U_pad, m->n_layers, max_wgs);
-            if (cap <= 0) continue;
+            if (lstm_persist_capacity(U_pad, 1, max_wgs) <= 0) continue;
+            // Layer segments.  A launch holds every layer of its segment at once, so the slots it can take shrink with the layer count (3 x 512:
+            // 192 utterances, 4 x 512: 128, 5 x 512: 64), and a file that does not fit runs as several launches over chunks of its utterances, each
+            // walking the whole time axis of its longest utterance.  A deep stack is cheaper cut the other way: the first launch runs as many layers
+            // as still take ALL the utterances, the next one continues from its (complete) H plane -- its first layer multiplies that plane
+            // like any upper layer (ext_upward) --, and so on: one time axis per segment instead of one per chunk (5 x 512, 192 utterances:
+            // 3 chunks x 5 layers -> segments of 3 + 2 layers).  AM_LSTM_SEGMENTS=0 keeps one segment.
+            std::vector<std::pair<int, int>> segs;   // (first layer, layers)
+            {
+                static const bool seg_ok = env_int("AM_LSTM_SEGMENTS", 1) != 0;
+                int l0 = 0;
+                while (l0 < m->n_layers) {
+                    int nl = m->n_layers - l0;
+                    if (seg_ok) while (nl > 1 && lstm_persist_capacity(U_pad, nl, max_wgs, l0 > 0) < n_utts) --nl;
+                    segs.emplace_back(l0, nl);
+                    l0 += nl;
+                }
+                // (a cut buys nothing when every segment still needs as many chunks as the whole stack would: keep the stack whole then)
+                const int cap_all = lstm_persist_capacity(U_pad, m->n_layers, max_wgs);
+                if (segs.size() > 1 && cap_all > 0) {
+                    size_t launches = 0;
+                    for (auto& sg : segs) { const int c = lstm_persist_capacity(U_pad, sg.second, max_wgs, sg.first > 0); launches += c > 0 ? (n_utts + c - 1) / c : 1u << 20; }
+                    if (launches >= (size_t)(n_utts + cap_all - 1) / cap_all) { segs.clear(); segs.emplace_back(0, m->n_layers); }
+                }
+            }
             bool ok = true;
-            for (int base = 0; base < n_utts && ok; base += cap) {
-                LstmPersistArgs pa{};
-                pa.n_layers = m->n_layers; pa.U_pad = U_pad; pa.T = (int)T; pa.slot_base = base; pa.slot_cap = std::min(cap, n_utts - base);
-                pa.max_wgs = max_wgs;
-                if (!plan_lstm_persist(pa, pa.slot_cap, nact.data(), nullptr)) { ok = false; break; }
-                staging.emplace_back(lstm_persist_cum_size(pa));
-                plan_lstm_persist(pa, pa.slot_cap, nact.data(), staging.back().data());
-                if (env_int("AM_LSTM_TEST_TIMEOUT", 0) != 0)   // test hook: an arrival target nobody can reach -> the bounded waits must give up
-                    for (int64_t t = 0; t < T; ++t) staging.back()[(size_t)(pa.n_groups_total - 1) * T + t] += 1;
-                pl.cums.emplace_back();
-                AM_TRY(pl.cums.back().ensure(sizeof(unsigned) * staging.back().size()));
-                HIP_TRY(hipMemcpyAsync(pl.cums.back().p, staging.back().data(), sizeof(unsigned) * staging.back().size(), hipMemcpyHostToDevice, e->stream));
-                pl.chunks.push_back(pa);
+            for (auto& sg : segs) {
+                const int cap = lstm_persist_capacity(U_pad, sg.second, max_wgs, sg.first > 0);
+                if (cap <= 0) { ok = false; break; }
+                for (int base = 0; base < n_utts && ok; base += cap) {
+                    LstmPersistArgs pa{};
+                    pa.n_layers = sg.second; pa.U_pad = U_pad; pa.T = (int)T; pa.slot_base = base; pa.slot_cap = std::min(cap, n_utts - base);
+                    pa.max_wgs = max_wgs; pa.ext_upward = sg.first > 0 ? 1 : 0;
+                    if (!plan_lstm_persist(pa, pa.slot_cap, nact.data(), nullptr)) { ok = false; break; }
+                    staging.emplace_back(lstm_persist_cum_size(pa));
+                    plan_lstm_persist(pa, pa.slot_cap, nact.data(), staging.back().data());
+                    if (env_int("AM_LSTM_TEST_TIMEOUT", 0) != 0)   // test hook: an arrival target nobody can reach -> the bounded waits must give up
+                        for (int64_t t = 0; t < T; ++t) staging.back()[(size_t)(pa.n_groups_total - 1) * T + t] += 1;
+                    pl.cums.emplace_back();
+                    AM_TRY(pl.cums.back().ensure(sizeof(unsigned) * staging.back().size()));
+                    HIP_TRY(hipMemcpyAsync(pl.cums.back().p, staging.back().data(), sizeof(unsigned) * staging.back().size(), hipMemcpyHostToDevice, e->stream));
+                    pl.chunks.push_back(pa);
+                    pl.layer0.push_back(sg.first);
+                }
+                if (!ok) break;
             }
             if (ok) { pl.form = 1; any_persist = true; } else pl.release();
         }
@@ -1792,9 +1822,10 @@ static int lstm_enqueue(am_pipeline* p)
             const size_t n_chunks = p->persist[mi].chunks.size();
             for (size_t ci = 0; ci < n_chunks; ++ci) {
                 LstmPersistArgs pa = p->persist[mi].chunks[ci];
-                for (int l = 0; l < NL; ++l) {
+                const int lbase = p->persist[mi].layer0[ci];   // (launches run in the order planned: a segment starts when the one below it is complete)
+                for (int l = lbase; l < lbase + pa.n_layers; ++l) {
                     Layer& Ly = m->L[l];
-                    LstmPersistLayer& s = pa.L[l];
+                    LstmPersistLayer& s = pa.L[l - lbase];
                     s.G = l == 0 ? p->d_G.as<float>() : nullptr;
                     s.bias = Ly.b.as<float>(); s.Wup = l == 0 ? nullptr : Ly.W.as<float>(); s.Wlat = Ly.Wlat.as<float>();
                     s.Hin = l == 0 ? nullptr : Hall + (l - 1) * h_stride;

@@ -167,6 +167,8 @@ struct LstmPersistArgs {
     int n_groups_total;            // grid = n_groups_total * (U_pad / 16)
     int max_wgs;                   // workgroups of this kernel the device holds at once (lstm_persist_resident_wgs): the plan's budget
     int slot_base, slot_cap;       // this launch covers the utterance slots [slot_base, slot_base + slot_cap) (longest first: a chunk of a larger file)
+    int ext_upward;                // 1: L[0] is not the stack's first layer -- it multiplies an upward input plane (L[0].Hin) that an EARLIER launch has
+                                   // completed (a deep stack run as several launches over layer ranges), instead of adding hoisted rows (L[0].G)
     const int* n_active;           // device [T]
     const int* step_off;           // device [T + 1]
     const unsigned* cum;           // device [n_groups_total][T]: arrivals group g has made once its step t is complete
@@ -179,7 +181,7 @@ struct LstmPersistArgs {
 bool plan_lstm_persist(LstmPersistArgs& a, int n_slots, const int* n_active_host, unsigned* cum_out /*nullable*/);
 size_t lstm_persist_cum_size(const LstmPersistArgs& a);   // entries of `cum`
 int lstm_persist_resident_wgs(int U_pad, int n_cus);      // co-resident workgroups of the kernel on a device of n_cus CUs (0: none)
-int lstm_persist_capacity(int U_pad, int n_layers, int max_wgs);   // utterance slots one launch can take (0: this shape has no persistent form)
+int lstm_persist_capacity(int U_pad, int n_layers, int max_wgs, bool ext_upward = false);   // utterance slots one launch can take (0: this shape has no persistent form)
 hipError_t launch_lstm_persist(hipStream_t s, const LstmPersistArgs& a);
 
 int lstm_persist_mode();   // AM_LSTM_PERSIST: 0 per-step kernels, 1 (default) the persistent form

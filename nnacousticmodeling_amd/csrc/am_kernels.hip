@@ -1727,7 +1727,8 @@ __device__ __forceinline__ bool persist_step(const LstmPersistArgs& a, const Lst
     const unsigned r_t = off_t + (unsigned)slot0;               // its packed row at step t (off_t = step_off[t], fetched a step ahead by the caller)
     const unsigned r_p = off_p + (unsigned)slot0;               // ... and at step t - 1 (h and c of the previous step; unused at t == 0)
     persist_stamp(a, gidx, ut, t, 0);
-    if (NBU) {   // upward product: needs step t of the layer below (which runs ahead: normally no wait at all)
+    if (NBU && li > 0) {   // upward product: needs step t of the layer below (which runs ahead: normally no wait at all; li == 0 with an
+                           // upward product: the segment's first layer, its input plane was completed by an earlier launch)
         if (!persist_wait(a, a.L[li - 1].group0, a.L[li - 1].n_groups, t, s_flag)) return false;
     }
     persist_stamp(a, gidx, ut, t, 1);
@@ -1869,7 +1870,8 @@ __device__ __forceinline__ bool persist_step_wide(const LstmPersistArgs& a, cons
     const unsigned r_t = off_t + (unsigned)slot0;
     const unsigned r_p = off_p + (unsigned)slot0;              // (t == 0: unused)
     const bool lat = t > 0;
-    const LstmPersistLayer& Lb = a.L[li - 1];
+    const bool ext = li == 0;                                   // a segment's first layer: its upward input is a plane an earlier launch has completed
+    const LstmPersistLayer& Lb = a.L[ext ? 0 : li - 1];
     // tile row of instruction e: wave + 8 e, so row & 15 takes two values per wave
     // (buffer form of the LDS-DMA: the per-lane part of the address is one of two 32-bit offsets, everything else is scalar -- no 64-bit vector
     // address per instruction, which the register budget of this kernel does not have)
@@ -1892,7 +1894,7 @@ __device__ __forceinline__ bool persist_step_wide(const LstmPersistArgs& a, cons
     constexpr unsigned TB = TLD * 4u;                    // bytes of a tile row: the second 256-k tile of a product starts there
     persist_stamp(a, gidx, ut, t, 0);
     if (have < 1) {
-        if (!persist_wait(a, Lb.group0, Lb.n_groups, t, s_flag)) return false;
+        if (!ext && !persist_wait(a, Lb.group0, Lb.n_groups, t, s_flag)) return false;
         dma_tile(uprs, up0, smem + OFF0);
     }
     const bool t1_here = have < 2;
@@ -1947,11 +1949,11 @@ __device__ __forceinline__ bool persist_step_wide(const LstmPersistArgs& a, cons
             if (!persist_wait_seen(a, Ly.group0, Ly.n_groups, seenL, tgtL, s_flag)) return false;
             // few rows: registers to spare and short batches -- the previous cell state is requested here (many rows: under the last tile's MFMAs)
             if (THIN) load_c();
-            if (want_next) peek(Lb.group0, Lb.n_groups, t + 1, pk + 128);   // (both before the tiles: b == 2's counted wait must cover them)
+            if (want_next && !ext) peek(Lb.group0, Lb.n_groups, t + 1, pk + 128);   // (both before the tiles: b == 2's counted wait must cover them)
             if (THIN) { dma_tile(hrs, lat0, smem + OFF2); dma_tile(hrs, lat0 + TB, smem + OFF3); }   // few rows: the step is a chain of latencies, both lateral tiles leave at once
         } else {
             if (b == 2 && tid < 64) {                              // has the layer below finished step t + 1?
-                const bool all = want_next && __builtin_amdgcn_ballot_w64(pk[128 + lane] < pk[192 + lane]) == 0ull;
+                const bool all = want_next && (ext || __builtin_amdgcn_ballot_w64(pk[128 + lane] < pk[192 + lane]) == 0ull);
                 if (tid == 0) s_flag[1] = (want_next && all) ? 1 : 0;
             }
             __builtin_amdgcn_s_barrier();
@@ -2191,7 +2193,7 @@ __global__ __launch_bounds__(512, 2) void lstm_persist_kernel(const LstmPersistA
 #pragma unroll
     for (int l = 1; l < LSTM_MAX_LAYERS; ++l) if (l < a.n_layers && gidx >= a.L[l].group0) li = l;
     const LstmPersistLayer& Ly = a.L[li];
-    if (li > 0) persist_body<NB, NB, lstm_persist_ntmax(NB, true)>(a, Ly, li, gidx, ut, persist_smem, s_flag);
+    if (li > 0 || a.ext_upward) persist_body<NB, NB, lstm_persist_ntmax(NB, true)>(a, Ly, li, gidx, ut, persist_smem, s_flag);
     else persist_body<0, NB, lstm_persist_ntmax(NB, false)>(a, Ly, li, gidx, ut, persist_smem, s_flag);
 }
 
@@ -2227,7 +2229,7 @@ int lstm_persist_resident_wgs(int U_pad, int n_cus)
     return per_cu > 0 ? n_cus : 0;   // the groups are laid out one workgroup per CU even where two would fit
 }
 
-int lstm_persist_capacity(int U_pad, int n_layers, int max_wgs)
+int lstm_persist_capacity(int U_pad, int n_layers, int max_wgs, bool ext_upward)
 {
     if ((U_pad != 256 && U_pad != 512) || n_layers < 1 || n_layers > LSTM_MAX_LAYERS) return 0;
     if (!lstm_persist_scratch_free(U_pad)) return 0;
@@ -2235,7 +2237,7 @@ int lstm_persist_capacity(int U_pad, int n_layers, int max_wgs)
     int tiles = 0;
     for (int t0 = 1; t0 <= 4096; ++t0) {
         int total = 0;
-        for (int l = 0; l < n_layers; ++l) { const int ntmax = lstm_persist_ntmax(nb, l > 0); total += (t0 + ntmax - 1) / ntmax; }
+        for (int l = 0; l < n_layers; ++l) { const int ntmax = lstm_persist_ntmax(nb, l > 0 || ext_upward); total += (t0 + ntmax - 1) / ntmax; }
         if (total > budget) break;
         tiles = t0;
     }
@@ -2250,7 +2252,7 @@ bool plan_lstm_persist(LstmPersistArgs& a, int n_slots, const int* n_active, uns
     const int tiles0 = (n_slots + 15) / 16;
     int ng[LSTM_MAX_LAYERS], total = 0;
     for (int l = 0; l < a.n_layers; ++l) {
-        const int ntmax = lstm_persist_ntmax(nb, l > 0);
+        const int ntmax = lstm_persist_ntmax(nb, l > 0 || a.ext_upward != 0);
         ng[l] = (tiles0 + ntmax - 1) / ntmax;
         total += ng[l];
     }
@@ -2261,7 +2263,7 @@ bool plan_lstm_persist(LstmPersistArgs& a, int n_slots, const int* n_active, uns
         int best = -1; long best_w = 0;
         for (int l = 0; l < a.n_layers; ++l) {
             if (ng[l] >= tiles0) continue;
-            const long wk = (long)(l > 0 ? 2 * nb : nb) * ((tiles0 + ng[l] - 1) / ng[l]);
+            const long wk = (long)((l > 0 || a.ext_upward) ? 2 * nb : nb) * ((tiles0 + ng[l] - 1) / ng[l]);
             if (wk > best_w) { best_w = wk; best = l; }
         }
         if (best < 0) break;

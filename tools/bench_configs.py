@@ -118,6 +118,20 @@ def main():
         wall, ms, calls = timed(eng, p.lstm_run, args.steps, 3)
         report("3x256 LSTM N=57919 192 utts", N, wall, ms, calls, 2 * (40 * 1024 + 2 * 256 * 1024 + 3 * 256 * 1024 + 256 * 1909))
         p.close()
+    if args.which in ("lstmshapes",):
+        # the LSTM shapes of the reference's recipes (scripts/papers/tsd2018/run.sh:33-41: 2..6 layers x 256 / 512; specom2018: 4 x 1024), --timedelay 5
+        for layers, units in ((2, 256), (6, 256), (2, 512), (3, 512), (4, 512), (5, 512), (4, 1024)):
+            params = orc.make_lstm_params(rng, 40, units, layers, 1909)
+            m = Model(eng, "lstm", layers, params)
+            p = Pipeline(eng)
+            p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
+            p.set_members([m])
+            p.lstm_upload(x, None, offsets, 5)
+            wall, ms, calls = timed(eng, p.lstm_run, args.steps, 3)
+            fl = 2 * (40 * 4 * units + layers * units * 4 * units + (layers - 1) * units * 4 * units + units * 1909)
+            report("%dx%d LSTM N=57919 192 utts timedelay=5 (%d of %d members persistent)" % ((layers, units) + p.recurrent_form()), N, wall, ms, calls, fl)
+            p.close()
+            m.close()
     if args.which in ("lstm1024",):
         # the reference's own example network (scripts/examples: "lstm -l 4 -u 1024 --timedelay 5")
         params = orc.make_lstm_params(rng, 40, 1024, 4, 1909)
