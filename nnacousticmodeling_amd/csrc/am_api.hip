@@ -2081,7 +2081,9 @@ struct am_decoder {
     bool has_compact = false;
     int form = AM_VITERBI_AUTO;   // am_decoder_set_form
     int perm = 0, inv0 = 0;   // compact records stored in arrival-list order (see ViterbiArgs::perm)
-    DevBuf d_lp, d_off, pp, tt, pout, p, bestI, bestT, seg_begin, seg_end, seg_tri, seg_count;
+    DevBuf d_lp, d_off, pp, tt, pout, p, p2, inv0_state, bestI, bestT, seg_begin, seg_end, seg_tri, seg_count;
+    DevBuf blk_tri0, blk_node0;   // fused frame-synchronous form (viterbi_fs_fused_kernel): blocks of whole arrival lists, <= 2,048 triphones each
+    int n_blk = 0;
 };
 
 template <class Tt>
@@ -2163,6 +2165,22 @@ extern "C" int am_decoder_create(am_engine* e, int numPhones, int numBiphones, i
             return rc;
         }
         d->has_compact = true;
+        if (is_perm) {
+            // blocks of the fused form: whole arrival lists, greedily packed up to 2,048 triphones (a longer list: no fused form)
+            std::vector<int> bt{0}, bn{0};
+            bool fits = true;
+            int cur = 0;
+            for (int i = 0; i < B && fits; ++i) {
+                const int len = outOffsets[i + 1] - outOffsets[i];
+                if (len > 2048) fits = false;
+                if (cur + len > 2048) { bt.push_back(outOffsets[i]); bn.push_back(i); cur = 0; }
+                cur += len;
+            }
+            bt.push_back(T); bn.push_back(B);
+            if (fits && (rc = upload_raw(e, d->blk_tri0, bt.data(), bt.size())) == AM_OK && (rc = upload_raw(e, d->blk_node0, bn.data(), bn.size())) == AM_OK)
+                d->n_blk = (int)bt.size() - 1;
+            if (rc != AM_OK) { am_decoder_destroy(d); return rc; }
+        }
     }
     if ((rc = upload_raw(e, d->endIdx, endIdxs, P)) == AM_OK && (rc = upload_raw(e, d->tri_idx, tidx.data(), tidx.size())) == AM_OK &&
         (rc = upload_raw(e, d->tri_self, tself.data(), tself.size())) == AM_OK && (rc = upload_raw(e, d->tri_trans, ttrans.data(), ttrans.size())) == AM_OK &&
@@ -2188,7 +2206,7 @@ extern "C" int am_decoder_destroy(am_decoder* d)
     (void)hipSetDevice(d->e->device);
     (void)hipStreamSynchronize(d->e->stream);
     for (DevBuf* b : {&d->d_slot, &d->cmp0, &d->cmp1, &d->endIdx, &d->tri_idx, &d->tri_self, &d->tri_trans, &d->outOff, &d->outVal, &d->lm, &d->p0, &d->d_lp, &d->d_off,
-                      &d->pp, &d->tt, &d->pout, &d->p, &d->bestI, &d->bestT, &d->seg_begin, &d->seg_end, &d->seg_tri, &d->seg_count})
+                      &d->pp, &d->tt, &d->pout, &d->p, &d->p2, &d->inv0_state, &d->blk_tri0, &d->blk_node0, &d->bestI, &d->bestT, &d->seg_begin, &d->seg_end, &d->seg_tri, &d->seg_count})
         b->release();
     am_engine* e = d->e;
     delete d;
@@ -2212,6 +2230,8 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
     AM_TRY(d->tt.ensure(sizeof(int) * T4 * std::max(n_utts, 1)));
     AM_TRY(d->pout.ensure(sizeof(float) * (size_t)d->T * std::max(n_utts, 1)));
     AM_TRY(d->p.ensure(sizeof(float) * (size_t)d->B * std::max(n_utts, 1)));
+    AM_TRY(d->p2.ensure(sizeof(float) * (size_t)d->B * std::max(n_utts, 1)));
+    AM_TRY(d->inv0_state.ensure(sizeof(int) * 16 * (size_t)std::max(n_utts, 1)));
     AM_TRY(d->bestI.ensure(std::max<size_t>(sizeof(int) * (size_t)N * d->B, 16)));
     AM_TRY(d->bestT.ensure(std::max<size_t>(sizeof(int) * (size_t)N * d->B, 16)));
     for (DevBuf* b : {&d->seg_begin, &d->seg_end, &d->seg_tri}) AM_TRY(b->ensure(std::max<size_t>(sizeof(int) * (size_t)N, 16)));
@@ -2235,6 +2255,8 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
     a.outOff = d->outOff.as<int>(); a.outVal = d->outVal.as<int>();
     a.lm = d->lm.as<float>(); a.p0 = d->p0.as<float>(); a.PIP = d->PIP;
     a.lp = lp_dev; a.ldl = ld; a.offsets = d->d_off.as<long long>();
+    a.p2 = d->p2.as<float>(); a.inv0_state = d->inv0_state.as<int>();
+    a.blk_tri0 = d->blk_tri0.as<int>(); a.blk_node0 = d->blk_node0.as<int>(); a.n_blk = d->n_blk;
     a.pp = d->pp.as<float>(); a.tt = d->tt.as<int>(); a.pout = d->pout.as<float>(); a.p = d->p.as<float>(); a.bestI = d->bestI.as<int>(); a.bestT = d->bestT.as<int>();
     a.seg_begin = d->seg_begin.as<int>(); a.seg_end = d->seg_end.as<int>(); a.seg_tri = d->seg_tri.as<int>(); a.seg_count = d->seg_count.as<int>();
     static const int64_t fs_env = env_int("AM_VITERBI_FS", 1);

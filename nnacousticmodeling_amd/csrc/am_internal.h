@@ -232,6 +232,13 @@ struct ViterbiArgs {
     int* seg_begin; int* seg_end; int* seg_tri;  // [N] segments of utterance u at [offsets[u], offsets[u] + seg_count[u]), last first
     int* seg_count;                    // [n_utts]
     const int* slot_utt;               // frame-synchronous form: utterance of each slot (slots sorted by length, longest first)
+    // frame-synchronous form: the node scores ping-pong between `p` (read by even frames, written by odd ones) and `p2` (the reverse), so that a
+    // launch that updates triphones AND takes the node maxima never overwrites a score another block of the same frame still has to read
+    float* p2;
+    // fused form (viterbi_fs_fused_kernel; perm == 1): block b covers the whole arrival lists of nodes [blk_node0[b], blk_node0[b+1]) =
+    // triphones [blk_tri0[b], blk_tri0[b+1]) (at most 2,048); inv0_state: [n_utts][2][8] ints, the state of triphone inv0 BEFORE frame k at parity k & 1
+    const int* blk_tri0; const int* blk_node0; int n_blk;
+    int* inv0_state;
 };
 hipError_t launch_viterbi(hipStream_t s, const ViterbiArgs& a, int n_utts);
 // frame-synchronous form (compact records only): init, one (triphone update + node maxima) launch pair per frame k over the

@@ -3086,6 +3086,10 @@ __global__ __launch_bounds__(256) void viterbi_fs_init_kernel(const ViterbiArgs 
     float* p = a.p + (size_t)slot * a.B;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.T; i += gridDim.x * 256) { pp[i] = (i32x4){ninf, ninf, ninf, 1 | (1 << 16)}; t2[i] = 1; }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.B; i += gridDim.x * 256) p[i] = a.p0[i];
+    if (a.inv0_state && blockIdx.x == 0 && threadIdx.x == 0) {
+        int* st = a.inv0_state + (size_t)slot * 16;   // parity 0: the state before frame 0
+        st[0] = ninf; st[1] = ninf; st[2] = ninf; st[3] = 1 | (1 << 16); st[4] = 1;
+    }
 }
 
 // Frame-synchronous triphone update, operands gathered from global memory (the tail of a run, and graphs whose two gather arrays do not fit LDS).
@@ -3101,7 +3105,7 @@ __global__ __launch_bounds__(256) void viterbi_fs_tri_kernel(const ViterbiArgs a
     i32x4* pp = (i32x4*)a.pp + (size_t)slot * T;
     int* t2 = a.tt + (size_t)slot * T;
     float* pout = a.pout + (size_t)slot * T;
-    const float* p = a.p + (size_t)slot * a.B;
+    const float* p = ((k & 1) ? a.p2 : a.p) + (size_t)slot * a.B;
     const float* lp1 = a.lp + (size_t)(row0 + k) * a.ldl;
     const i32x4* c0 = (const i32x4*)a.tri_idx;
     const f32x4* c1 = (const f32x4*)a.tri_self;
@@ -3130,7 +3134,7 @@ __global__ __launch_bounds__(256) void viterbi_fs_tri_lds_kernel(const ViterbiAr
     const int slot = blockIdx.y, T = a.T, B = a.B, L = (int)a.ldl;
     const long long row0 = a.offsets[a.slot_utt[slot]];
     const float* lp1 = a.lp + (size_t)(row0 + k) * a.ldl;
-    const float* p = a.p + (size_t)slot * B;
+    const float* p = ((k & 1) ? a.p2 : a.p) + (size_t)slot * B;
     i32x4* pp = (i32x4*)a.pp + (size_t)slot * T;
     int* t2 = a.tt + (size_t)slot * T;
     float* pout = a.pout + (size_t)slot * T;
@@ -3208,9 +3212,108 @@ __global__ __launch_bounds__(256) void viterbi_fs_node_kernel(const ViterbiArgs 
     if (valid && l8 == 0) {
         if (ms == 0x7fffffff) mxi = a.perm ? a.inv0 : 0;   // nothing exceeded -1e20: the reference keeps its triphone 0
         const long long row = a.offsets[a.slot_utt[slot]] + k;
-        a.p[(size_t)slot * a.B + i] = mx + a.lm[i];
+        ((k & 1) ? a.p : a.p2)[(size_t)slot * a.B + i] = mx + a.lm[i];
         a.bestI[(size_t)row * a.B + i] = mxi;
         a.bestT[(size_t)row * a.B + i] = a.tt[(size_t)slot * a.T + mxi] - 1;
+    }
+}
+
+// Triphone update AND node maxima of a frame in ONE launch (round 3).  With the triphones stored in arrival-list order a node's arrivals are
+// consecutive triphones; block b takes the whole lists of nodes [blk_node0[b], blk_node0[b+1]) -- at most 2,048 triphones, cut on node
+// boundaries by the host -- so every maximum is taken inside one block, from LDS, right behind the update: no exit-score array written and read
+// back (8 of the 48 B a triphone moved per frame), no second launch per frame.  The node scores ping-pong between two arrays by frame parity (a
+// block of the same launch may still have to stage the old ones).  A node none of whose arrivals exceeds -1e20 keeps the reference's triphone 0
+// and that triphone's NEW entry time (phone_recog.cpp:190-200), which another block may not have produced yet: it is recomputed here from the
+// triphone's state before this frame, which its owner leaves in `inv0_state` every frame (parity again).
+__global__ __launch_bounds__(256) void viterbi_fs_fused_kernel(const ViterbiArgs a, int k)
+{
+    constexpr int IT = 4, CAP = IT * 512;
+    extern __shared__ float vsm[];                          // [ldl] log-posteriors of frame k, [B] node scores, [CAP] exit scores, [CAP] entry times
+    const int slot = blockIdx.y, T = a.T, B = a.B, L = (int)a.ldl;
+    const int tri0 = a.blk_tri0[blockIdx.x], tri1 = a.blk_tri0[blockIdx.x + 1];
+    const int node0 = a.blk_node0[blockIdx.x], node1 = a.blk_node0[blockIdx.x + 1];
+    const long long row = a.offsets[a.slot_utt[slot]] + k;
+    const float* lp1 = a.lp + (size_t)row * a.ldl;
+    const float* p = ((k & 1) ? a.p2 : a.p) + (size_t)slot * B;
+    float* pnext = ((k & 1) ? a.p : a.p2) + (size_t)slot * B;
+    i32x4* pp = (i32x4*)a.pp + (size_t)slot * T;
+    int* t2 = a.tt + (size_t)slot * T;
+    const i32x4* c0 = (const i32x4*)a.tri_idx;
+    const f32x4* c1 = (const f32x4*)a.tri_self;
+    float* s_lp = vsm;
+    float* s_p = vsm + L;
+    float* s_po = s_p + B;
+    int* s_t2 = (int*)(s_po + CAP);
+    const int base = tri0 + threadIdx.x;
+    i32x4 ga[IT], gb[IT], qa[IT], qb[IT]; f32x4 ha[IT], hb[IT]; int ta[IT], tb[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int n0 = base + it * 512;
+        const int n = n0 < tri1 ? n0 : tri1 - 1, m = n0 + 256 < tri1 ? n0 + 256 : tri1 - 1;   // (past the block's end: repeats its last triphone's loads, stores nothing)
+        ga[it] = c0[n]; gb[it] = c0[m]; ha[it] = c1[n]; hb[it] = c1[m];
+        qa[it] = pp[n]; qb[it] = pp[m]; ta[it] = t2[n]; tb[it] = t2[m];
+    }
+    for (int i = threadIdx.x; i < L; i += 256) s_lp[i] = lp1[i];
+    for (int i = threadIdx.x; i < B; i += 256) s_p[i] = p[i];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int n = base + it * 512;
+        if (n >= tri1) break;
+        const bool two = n + 256 < tri1;
+        i32x4 nqa, nqb; int nta, ntb; float poa, pob;
+        {
+            const i32x4 g = ga[it];
+            viterbi_tri_apply(g, ha[it], qa[it], ta[it], s_p[g[0] & 0xffff], s_lp[(unsigned)g[0] >> 16], s_lp[g[1] & 0xffff], s_lp[(unsigned)g[1] >> 16], a.PIP, k, nqa, nta, poa);
+        }
+        {
+            const i32x4 g = gb[it];
+            viterbi_tri_apply(g, hb[it], qb[it], tb[it], s_p[g[0] & 0xffff], s_lp[(unsigned)g[0] >> 16], s_lp[g[1] & 0xffff], s_lp[(unsigned)g[1] >> 16], a.PIP, k, nqb, ntb, pob);
+        }
+        pp[n] = nqa; t2[n] = nta; s_po[n - tri0] = poa; s_t2[n - tri0] = nta;
+        if (two) { pp[n + 256] = nqb; t2[n + 256] = ntb; s_po[n + 256 - tri0] = pob; s_t2[n + 256 - tri0] = ntb; }
+        // the owner of the reference's triphone 0 leaves its state for the next frame's unreachable nodes
+        if (n == a.inv0 || (two && n + 256 == a.inv0)) {
+            const bool first = n == a.inv0;
+            int* st = a.inv0_state + (size_t)slot * 16 + ((k + 1) & 1) * 8;
+            const i32x4 q = first ? nqa : nqb;
+            st[0] = q[0]; st[1] = q[1]; st[2] = q[2]; st[3] = q[3]; st[4] = first ? nta : ntb;
+        }
+    }
+    __syncthreads();
+    // node maxima: 8 lanes per node, the first strict maximum in list order (the node kernel's code on the LDS copy)
+    const int l8 = threadIdx.x & 7;
+    for (int i0 = node0; i0 < node1; i0 += 32) {
+        const int i = i0 + (threadIdx.x >> 3);
+        const bool valid = i < node1;
+        const int s0 = valid ? a.outOff[i] : 0, s1 = valid ? a.outOff[i + 1] : 0;
+        float mx = -1e20f; int ms = 0x7fffffff, mxi = 0;
+        for (int s = s0 + l8; s < s1; s += 8) {
+            const float pOut = s_po[s - tri0];
+            if (mx < pOut) { mx = pOut; ms = s; mxi = s; }
+        }
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) {
+            const float omx = __shfl_xor(mx, off);
+            const int oms = __shfl_xor(ms, off), omi = __shfl_xor(mxi, off);
+            if (omx > mx || (omx == mx && oms < ms)) { mx = omx; ms = oms; mxi = omi; }
+        }
+        if (valid && l8 == 0) {
+            int bt;
+            if (ms == 0x7fffffff) {   // nothing exceeded -1e20: triphone inv0 and its entry time after THIS frame's update
+                mxi = a.inv0;
+                const int* st = a.inv0_state + (size_t)slot * 16 + (k & 1) * 8;
+                const f32x4 h0 = c1[a.inv0];
+                const float q1 = __int_as_float(st[1]), q2 = __int_as_float(st[2]);
+                const int t1s = (unsigned)st[3] >> 16, t2s = st[4];
+                bt = ((q1 + h0[2] > q2 + h0[0]) ? t1s : t2s) - 1;   // viterbi_tri_apply's nt2: go2 = q1 + tr1, st2 = q2 + sl2
+            } else {
+                bt = s_t2[mxi - tri0] - 1;
+            }
+            pnext[i] = mx + a.lm[i];
+            a.bestI[(size_t)row * B + i] = mxi;
+            a.bestT[(size_t)row * B + i] = bt;
+        }
     }
 }
 
@@ -3221,7 +3324,7 @@ __global__ __launch_bounds__(64) void viterbi_fs_trace_kernel(const ViterbiArgs 
     const int u = a.slot_utt[slot];
     const long long row0 = a.offsets[u];
     const int N = (int)(a.offsets[u + 1] - row0), B = a.B;
-    const float* p = a.p + (size_t)slot * B;
+    const float* p = ((N & 1) ? a.p2 : a.p) + (size_t)slot * B;   // frame N - 1 wrote the array of the other parity
     const int* bI = a.bestI + (size_t)row0 * B;
     const int* bT = a.bestT + (size_t)row0 * B;
     const i32x4* c0 = (const i32x4*)a.tri_idx;
@@ -3257,8 +3360,12 @@ hipError_t launch_viterbi_fs_init(hipStream_t s, const ViterbiArgs& a, int n_utt
 hipError_t launch_viterbi_fs_step(hipStream_t s, const ViterbiArgs& a, int k, int n_active)
 {
     if (n_active <= 0) return hipSuccess;
-    const char* sv = getenv("AM_VITERBI_LDS");       // (measurement: 0 = every launch on the form that gathers from global memory)
+    const char* sv = getenv("AM_VITERBI_LDS");       // (measurement: 0 = every launch on the form that gathers from global memory; 1 = staged, node maxima in their own launch)
     const size_t lds = ((size_t)a.ldl + (size_t)a.B) * sizeof(float);
+    if ((!sv || atoi(sv) > 1) && a.n_blk > 0 && a.perm && lds + 2 * 2048 * sizeof(float) <= 48 * 1024 && n_active >= 12) {
+        hipLaunchKernelGGL(viterbi_fs_fused_kernel, dim3(a.n_blk, n_active), dim3(256), lds + 2 * 2048 * sizeof(float), s, a, k);
+        return hipGetLastError();
+    }
     if ((!sv || atoi(sv) != 0) && lds <= 32 * 1024 && n_active >= 12) {
         // trips per thread: 4 (2,048 triphones per staging) while that still gives several blocks per CU, 2 towards the tail of the run
         const int trips = (a.T + 511) / 512;

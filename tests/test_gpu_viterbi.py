@@ -88,9 +88,9 @@ def test_larger_graphs_match_oracle(engine, P, S, PIP):
 
 @pytest.mark.parametrize("P,S", [(12, 300), (48, 1909)])
 def test_frame_sync_lds_form_matches_the_other_forms(engine, P, S, monkeypatch):
-    """With 12 or more active utterances the frame-synchronous triphone kernel stages the frame's log-posterior row and the node
-    scores in LDS (24 or more: 2,048 triphones per staging, else 1,024); below, and with AM_VITERBI_LDS=0, it gathers from
-    global memory.  40 utterances of 3..90 frames walk through all three; every form must give the oracle's segmentations
+    """With 12 or more active utterances the frame-synchronous form stages the frame's log-posterior row and the node scores in
+    LDS and takes the node maxima in the same launch (AM_VITERBI_LDS=1: in a launch of their own; 24 or more utterances: 2,048
+    triphones per staging, else 1,024); below 12, and with AM_VITERBI_LDS=0, it gathers from global memory.  40 utterances of 3..90 frames walk through all three; every form must give the oracle's segmentations
     (small graph) / the per-utterance kernel's (real-size graph: the oracle on a sample)."""
     from nnacousticmodeling_amd.phone_recog import PhoneRecog
     rng = np.random.default_rng(P * 7 + S)
@@ -101,13 +101,15 @@ def test_frame_sync_lds_form_matches_the_other_forms(engine, P, S, monkeypatch):
     lp = np.concatenate(lps)
     dec = PhoneRecog(engine, dict(graph, numPhones=P, numBiphones=len(graph["lm"]), numTriphones=len(graph["biphoneIdxIn"])), -6.0, 0.8)
     dec.set_form("frame_sync")
-    monkeypatch.setenv("AM_VITERBI_LDS", "1")
+    monkeypatch.setenv("AM_VITERBI_LDS", "2")   # the default: triphone update and node maxima in one launch (blocks of whole arrival lists)
+    fused = dec.recognise(lp, offsets)
+    monkeypatch.setenv("AM_VITERBI_LDS", "1")   # staged gathers, node maxima in their own launch
     staged = dec.recognise(lp, offsets)
     monkeypatch.setenv("AM_VITERBI_LDS", "0")
     gathered = dec.recognise(lp, offsets)
     dec.set_form("per_utt_compact")
     per_utt = dec.recognise(lp, offsets)
-    assert staged == gathered == per_utt
+    assert fused == staged == gathered == per_utt
     assert sum(len(r) for r in staged) > 40
     for u in (range(40) if P == 12 else (0, 17, 39)):
         want = [(b, e, graph["phones"][t]) for b, e, t in vo.recog_one(graph, lps[u], -6.0, 0.8)]
