@@ -3253,6 +3253,16 @@ __global__ __launch_bounds__(256) void viterbi_fs_fused_kernel(const ViterbiArgs
         ga[it] = c0[n]; gb[it] = c0[m]; ha[it] = c1[n]; hb[it] = c1[m];
         qa[it] = pp[n]; qb[it] = pp[m]; ta[it] = t2[n]; tb[it] = t2[m];
     }
+    // the list bounds and the language-model term of this thread's nodes (8 lanes per node, 32 nodes per round): requested here, with everything
+    // else, so that the node phase below does not start with a memory round trip of its own (the first two rounds; a block has ~54 nodes at the real size)
+    const int l8 = threadIdx.x & 7;
+    int ns0[2], ns1[2]; float nlm[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = node0 + r * 32 + (threadIdx.x >> 3);
+        const bool valid = i < node1;
+        ns0[r] = valid ? a.outOff[i] : 0; ns1[r] = valid ? a.outOff[i + 1] : 0; nlm[r] = valid ? a.lm[i] : 0.0f;
+    }
     for (int i = threadIdx.x; i < L; i += 256) s_lp[i] = lp1[i];
     for (int i = threadIdx.x; i < B; i += 256) s_p[i] = p[i];
     __syncthreads();
@@ -3282,11 +3292,12 @@ __global__ __launch_bounds__(256) void viterbi_fs_fused_kernel(const ViterbiArgs
     }
     __syncthreads();
     // node maxima: 8 lanes per node, the first strict maximum in list order (the node kernel's code on the LDS copy)
-    const int l8 = threadIdx.x & 7;
-    for (int i0 = node0; i0 < node1; i0 += 32) {
+    for (int i0 = node0, r = 0; i0 < node1; i0 += 32, ++r) {
         const int i = i0 + (threadIdx.x >> 3);
         const bool valid = i < node1;
-        const int s0 = valid ? a.outOff[i] : 0, s1 = valid ? a.outOff[i + 1] : 0;
+        const int s0 = r == 0 ? ns0[0] : r == 1 ? ns0[1] : (valid ? a.outOff[i] : 0);
+        const int s1 = r == 0 ? ns1[0] : r == 1 ? ns1[1] : (valid ? a.outOff[i + 1] : 0);
+        const float lmi = r == 0 ? nlm[0] : r == 1 ? nlm[1] : (valid ? a.lm[i] : 0.0f);
         float mx = -1e20f; int ms = 0x7fffffff, mxi = 0;
         for (int s = s0 + l8; s < s1; s += 8) {
             const float pOut = s_po[s - tri0];
@@ -3310,7 +3321,7 @@ __global__ __launch_bounds__(256) void viterbi_fs_fused_kernel(const ViterbiArgs
             } else {
                 bt = s_t2[mxi - tri0] - 1;
             }
-            pnext[i] = mx + a.lm[i];
+            pnext[i] = mx + lmi;
             a.bestI[(size_t)row * B + i] = mxi;
             a.bestT[(size_t)row * B + i] = bt;
         }
