@@ -309,6 +309,25 @@ def secondary_records(eng, ft, params, layers, x, steps):
                              "kernels_ms_per_pass": {k_: v[1] / kl for k_, v in prof.items()}}
         p.close()
         ml.close()
+    # (iv b) the reference's own recurrent recipe shape (scripts/papers/specom2018/run.sh:9: "-n lstm -l 4 -u 1024 --timedelay 5"): its weights do not fit
+    # the register file, so it runs on the per-step kernels (one launch per (layer, time) diagonal)
+    with _Guarded(out, "lstm_4x1024_td5"):
+        rng = np.random.default_rng(SEED + 6)
+        ml4 = Model(eng, "lstm", 4, make_lstm_params(rng, 40, 1024, 4, 1909))
+        p = Pipeline(eng)
+        p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
+        p.set_members([ml4])
+        p.lstm_upload(x[:n57], None, off, 5)
+        k4 = 3
+        wall, _, prof = timed_runs(eng, p.lstm_run, k4, 2, pipe=p)
+        fl = 2 * (40 * 4096 + 4 * 1024 * 4096 + 3 * 1024 * 4096 + 1024 * 1909)
+        out["lstm_4x1024_td5"] = {"value": n57 * k4 / wall, "unit": "frames/s", "ms_per_pass": wall * 1e3 / k4, "frames": n57, "utterances": 192,
+                                  "roofline": {"bound": "mfma (dependent time steps)", "kernel": "whole pass", "achieved": fl * n57 * k4 / wall / 1e12,
+                                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": fl * n57 * k4 / wall / 1e12 / PEAK_F32_MFMA_TFLOPS},
+                                  "recurrent_form": "%d of %d members as one persistent launch" % p.recurrent_form(),
+                                  "launches_per_pass": {k_: v[0] // k4 for k_, v in prof.items()}}
+        p.close()
+        ml4.close()
     # (v) BASELINE configs[4]: 10 fold members (4x1024 each), logits averaged on the device (evaluate.py:35-51) -- one GPU's share;
     # on a node the folds x utterances shard over the GPUs with no collective (sharding.py)
     with _Guarded(out, "ensemble_10x4x1024"):
