@@ -896,7 +896,9 @@ __device__ __forceinline__ float row_logsum(const float (&v)[NIT], int lane, int
 // n_in > 1: the members of an ensemble left their logits in n_in buffers (in + k * in_stride); they are combined here in member order with
 // the float operations of the one-buffer path -- v = in_0 (* first_scale: a master's weight, NNWithRPL); v = v + in_k -- or, with
 // member_norm (the dev-mode mean of log-posteriors, predict_folds.py:207-212), v = (in_0 - logsum(in_0)); v = v + (in_k - logsum(in_k)).
-template <int NIT>
+// (MULTI is an instantiation of its own: its second row of registers costs the one-buffer path occupancy -- 530 -> 622 us on the headline's
+// 196,608 x 1909 rows when both lived in one kernel)
+template <int NIT, bool MULTI>
 __global__ __launch_bounds__(256) void finish_kernel(
     const float* __restrict__ in, int ldin, float* __restrict__ out, long long ldout, const int* __restrict__ row_map,
     long long n, int C, float divisor, const float* __restrict__ rpl_w, const float* __restrict__ rpl_b,
@@ -913,7 +915,7 @@ __global__ __launch_bounds__(256) void finish_kernel(
     const float* src = in + row * ldin;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) { const int c = it * 64 + lane; v[it] = c < C ? src[c] : 0.0f; }
-    if (n_in > 1) {
+    if (MULTI && n_in > 1) {
         if (first_scale != 1.0f) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) v[it] = v[it] * first_scale;
@@ -979,8 +981,10 @@ hipError_t launch_finish(hipStream_t s, const FinishArgs& a)
     if (a.n <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((a.n + 3) / 4);
     const int nit = (a.C + 63) / 64;
-#define AM_FINISH(N) hipLaunchKernelGGL(finish_kernel<N>, dim3(blocks), dim3(256), 0, s, a.in, a.ldin, a.out, (long long)a.ldout, a.row_map, \
-        (long long)a.n, a.C, a.divisor, a.rpl_w, a.rpl_b, a.rpl_lb, a.prior, a.normalise, a.accumulate, a.n_in, (long long)a.in_stride, a.first_scale, a.member_norm)
+#define AM_FINISH_ARGS a.in, a.ldin, a.out, (long long)a.ldout, a.row_map, (long long)a.n, a.C, a.divisor, a.rpl_w, a.rpl_b, a.rpl_lb, a.prior, a.normalise, \
+        a.accumulate, a.n_in, (long long)a.in_stride, a.first_scale, a.member_norm
+#define AM_FINISH(N) do { if (a.n_in > 1) hipLaunchKernelGGL((finish_kernel<N, true>), dim3(blocks), dim3(256), 0, s, AM_FINISH_ARGS); \
+                          else hipLaunchKernelGGL((finish_kernel<N, false>), dim3(blocks), dim3(256), 0, s, AM_FINISH_ARGS); } while (0)
     if (nit <= 1) AM_FINISH(1);
     else if (nit <= 2) AM_FINISH(2);
     else if (nit <= 4) AM_FINISH(4);
@@ -990,6 +994,7 @@ hipError_t launch_finish(hipStream_t s, const FinishArgs& a)
     else if (nit <= 32) AM_FINISH(32);
     else return hipErrorInvalidValue;
 #undef AM_FINISH
+#undef AM_FINISH_ARGS
     return hipGetLastError();
 }
 
