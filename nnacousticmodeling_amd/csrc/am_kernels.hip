@@ -3256,7 +3256,7 @@ __global__ __launch_bounds__(256) void viterbi_fs_fused_kernel(const ViterbiArgs
         const int n0 = base + it * 512;
         const int n = n0 < tri1 ? n0 : tri1 - 1, m = n0 + 256 < tri1 ? n0 + 256 : tri1 - 1;   // (past the block's end: repeats its last triphone's loads, stores nothing)
         ga[it] = c0[n]; gb[it] = c0[m]; ha[it] = c1[n]; hb[it] = c1[m];
-        qa[it] = pp[n]; qb[it] = pp[m]; ta[it] = t2[n]; tb[it] = t2[m];
+        qa[it] = __builtin_nontemporal_load(pp + n); qb[it] = __builtin_nontemporal_load(pp + m); ta[it] = __builtin_nontemporal_load(t2 + n); tb[it] = __builtin_nontemporal_load(t2 + m);
     }
     // the list bounds and the language-model term of this thread's nodes (8 lanes per node, 32 nodes per round): requested here, with everything
     // else, so that the node phase below does not start with a memory round trip of its own (the first two rounds; a block has ~54 nodes at the real size)
@@ -3285,8 +3285,8 @@ __global__ __launch_bounds__(256) void viterbi_fs_fused_kernel(const ViterbiArgs
             const i32x4 g = gb[it];
             viterbi_tri_apply(g, hb[it], qb[it], tb[it], s_p[g[0] & 0xffff], s_lp[(unsigned)g[0] >> 16], s_lp[g[1] & 0xffff], s_lp[(unsigned)g[1] >> 16], a.PIP, k, nqb, ntb, pob);
         }
-        pp[n] = nqa; t2[n] = nta; s_po[n - tri0] = poa; s_t2[n - tri0] = nta;
-        if (two) { pp[n + 256] = nqb; t2[n + 256] = ntb; s_po[n + 256 - tri0] = pob; s_t2[n + 256 - tri0] = ntb; }
+        __builtin_nontemporal_store(nqa, pp + n); __builtin_nontemporal_store(nta, t2 + n); s_po[n - tri0] = poa; s_t2[n - tri0] = nta;
+        if (two) { __builtin_nontemporal_store(nqb, pp + n + 256); __builtin_nontemporal_store(ntb, t2 + n + 256); s_po[n + 256 - tri0] = pob; s_t2[n + 256 - tri0] = ntb; }
         // the owner of the reference's triphone 0 leaves its state for the next frame's unreachable nodes
         if (n == a.inv0 || (two && n + 256 == a.inv0)) {
             const bool first = n == a.inv0;
