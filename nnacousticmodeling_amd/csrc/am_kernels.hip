@@ -3230,9 +3230,10 @@ __global__ __launch_bounds__(256) void viterbi_fs_node_kernel(const ViterbiArgs 
 // block of the same launch may still have to stage the old ones).  A node none of whose arrivals exceeds -1e20 keeps the reference's triphone 0
 // and that triphone's NEW entry time (phone_recog.cpp:190-200), which another block may not have produced yet: it is recomputed here from the
 // triphone's state before this frame, which its owner leaves in `inv0_state` every frame (parity again).
-__global__ __launch_bounds__(256) void viterbi_fs_fused_kernel(const ViterbiArgs a, int k)
+template <int NTHR>
+__global__ __launch_bounds__(NTHR) void viterbi_fs_fused_kernel(const ViterbiArgs a, int k)
 {
-    constexpr int IT = 4, CAP = IT * 512;
+    constexpr int CAP = 2048, IT = CAP / (2 * NTHR), HALF = NTHR;   // a thread's triphones: n and n + HALF, IT times
     extern __shared__ float vsm[];                          // [ldl] log-posteriors of frame k, [B] node scores, [CAP] exit scores, [CAP] entry times
     const int slot = blockIdx.y, T = a.T, B = a.B, L = (int)a.ldl;
     const int tri0 = a.blk_tri0[blockIdx.x], tri1 = a.blk_tri0[blockIdx.x + 1];
@@ -3253,29 +3254,29 @@ __global__ __launch_bounds__(256) void viterbi_fs_fused_kernel(const ViterbiArgs
     i32x4 ga[IT], gb[IT], qa[IT], qb[IT]; f32x4 ha[IT], hb[IT]; int ta[IT], tb[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        const int n0 = base + it * 512;
-        const int n = n0 < tri1 ? n0 : tri1 - 1, m = n0 + 256 < tri1 ? n0 + 256 : tri1 - 1;   // (past the block's end: repeats its last triphone's loads, stores nothing)
+        const int n0 = base + it * 2 * HALF;
+        const int n = n0 < tri1 ? n0 : tri1 - 1, m = n0 + HALF < tri1 ? n0 + HALF : tri1 - 1;   // (past the block's end: repeats its last triphone's loads, stores nothing)
         ga[it] = c0[n]; gb[it] = c0[m]; ha[it] = c1[n]; hb[it] = c1[m];
         qa[it] = __builtin_nontemporal_load(pp + n); qb[it] = __builtin_nontemporal_load(pp + m); ta[it] = __builtin_nontemporal_load(t2 + n); tb[it] = __builtin_nontemporal_load(t2 + m);
     }
-    // the list bounds and the language-model term of this thread's nodes (8 lanes per node, 32 nodes per round): requested here, with everything
+    // the list bounds and the language-model term of this thread's nodes (8 lanes per node, NTHR / 8 nodes per round): requested here, with everything
     // else, so that the node phase below does not start with a memory round trip of its own (the first two rounds; a block has ~54 nodes at the real size)
     const int l8 = threadIdx.x & 7;
     int ns0[2], ns1[2]; float nlm[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int i = node0 + r * 32 + (threadIdx.x >> 3);
+        const int i = node0 + r * (NTHR / 8) + (threadIdx.x >> 3);
         const bool valid = i < node1;
         ns0[r] = valid ? a.outOff[i] : 0; ns1[r] = valid ? a.outOff[i + 1] : 0; nlm[r] = valid ? a.lm[i] : 0.0f;
     }
-    for (int i = threadIdx.x; i < L; i += 256) s_lp[i] = lp1[i];
-    for (int i = threadIdx.x; i < B; i += 256) s_p[i] = p[i];
+    for (int i = threadIdx.x; i < L; i += NTHR) s_lp[i] = lp1[i];
+    for (int i = threadIdx.x; i < B; i += NTHR) s_p[i] = p[i];
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        const int n = base + it * 512;
+        const int n = base + it * 2 * HALF;
         if (n >= tri1) break;
-        const bool two = n + 256 < tri1;
+        const bool two = n + HALF < tri1;
         i32x4 nqa, nqb; int nta, ntb; float poa, pob;
         {
             const i32x4 g = ga[it];
@@ -3286,9 +3287,9 @@ __global__ __launch_bounds__(256) void viterbi_fs_fused_kernel(const ViterbiArgs
             viterbi_tri_apply(g, hb[it], qb[it], tb[it], s_p[g[0] & 0xffff], s_lp[(unsigned)g[0] >> 16], s_lp[g[1] & 0xffff], s_lp[(unsigned)g[1] >> 16], a.PIP, k, nqb, ntb, pob);
         }
         __builtin_nontemporal_store(nqa, pp + n); __builtin_nontemporal_store(nta, t2 + n); s_po[n - tri0] = poa; s_t2[n - tri0] = nta;
-        if (two) { __builtin_nontemporal_store(nqb, pp + n + 256); __builtin_nontemporal_store(ntb, t2 + n + 256); s_po[n + 256 - tri0] = pob; s_t2[n + 256 - tri0] = ntb; }
+        if (two) { __builtin_nontemporal_store(nqb, pp + n + HALF); __builtin_nontemporal_store(ntb, t2 + n + HALF); s_po[n + HALF - tri0] = pob; s_t2[n + HALF - tri0] = ntb; }
         // the owner of the reference's triphone 0 leaves its state for the next frame's unreachable nodes
-        if (n == a.inv0 || (two && n + 256 == a.inv0)) {
+        if (n == a.inv0 || (two && n + HALF == a.inv0)) {
             const bool first = n == a.inv0;
             int* st = a.inv0_state + (size_t)slot * 16 + ((k + 1) & 1) * 8;
             const i32x4 q = first ? nqa : nqb;
@@ -3297,7 +3298,7 @@ __global__ __launch_bounds__(256) void viterbi_fs_fused_kernel(const ViterbiArgs
     }
     __syncthreads();
     // node maxima: 8 lanes per node, the first strict maximum in list order (the node kernel's code on the LDS copy)
-    for (int i0 = node0, r = 0; i0 < node1; i0 += 32, ++r) {
+    for (int i0 = node0, r = 0; i0 < node1; i0 += NTHR / 8, ++r) {
         const int i = i0 + (threadIdx.x >> 3);
         const bool valid = i < node1;
         const int s0 = r == 0 ? ns0[0] : r == 1 ? ns0[1] : (valid ? a.outOff[i] : 0);
@@ -3379,7 +3380,10 @@ hipError_t launch_viterbi_fs_step(hipStream_t s, const ViterbiArgs& a, int k, in
     const char* sv = getenv("AM_VITERBI_LDS");       // (measurement: 0 = every launch on the form that gathers from global memory; 1 = staged, node maxima in their own launch)
     const size_t lds = ((size_t)a.ldl + (size_t)a.B) * sizeof(float);
     if ((!sv || atoi(sv) > 1) && a.n_blk > 0 && a.perm && lds + 2 * 2048 * sizeof(float) <= 48 * 1024 && n_active >= 12) {
-        hipLaunchKernelGGL(viterbi_fs_fused_kernel, dim3(a.n_blk, n_active), dim3(256), lds + 2 * 2048 * sizeof(float), s, a, k);
+        // 512 threads x 4 triphones: 50.8 ms per real-size pass; 256 x 8: 52.7; 1,024 x 2: 59.2 (AM_VITERBI_THREADS=256 for A/B timing)
+        const char* tv = getenv("AM_VITERBI_THREADS");
+        if (tv && atoi(tv) == 256) hipLaunchKernelGGL(viterbi_fs_fused_kernel<256>, dim3(a.n_blk, n_active), dim3(256), lds + 2 * 2048 * sizeof(float), s, a, k);
+        else hipLaunchKernelGGL(viterbi_fs_fused_kernel<512>, dim3(a.n_blk, n_active), dim3(512), lds + 2 * 2048 * sizeof(float), s, a, k);
         return hipGetLastError();
     }
     if ((!sv || atoi(sv) != 0) && lds <= 32 * 1024 && n_active >= 12) {
