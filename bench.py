@@ -416,10 +416,10 @@ def secondary_records(eng, ft, params, layers, x, steps):
         eng.profile(False)
         vit_ms = pass_ms                   # the roofline figure: the whole pass as it runs in production, launch gaps included
         steps_v = int(np.diff(off).max())
-        # HBM bytes the pass cannot avoid: per (utterance, frame) the state of every triphone read (20 B) and written (20 B: the exit scores
+        # HBM bytes the pass cannot avoid: per (utterance, frame) the state of every triphone read (18 B: 3 scores, 3 16-bit entry times) and written (18 B: the exit scores
         # stay in LDS since the node maxima are taken in the same launch), the node back-pointers (8 B) and the frame's posterior row; per
         # frame-launch the graph constants once (32 B per triphone, shared by all utterances of the launch: L2 / Infinity Cache serve the repeats)
-        vit_bytes = n57 * (T_ * 40 + B_ * 8 + 1909 * 4) + steps_v * T_ * 32
+        vit_bytes = n57 * (T_ * 36 + B_ * 8 + 1909 * 4) + steps_v * T_ * 32
         out["viterbi_realsize"] = {"value": n57 / (vit_ms * 1e-3), "unit": "frames/s (device time of the pass)", "pass_ms": vit_ms,
                                    "kernel_ms_sum_with_an_event_pair_per_launch": vprof["viterbi"][1], "launches": vprof["viterbi"][0],
                                    "host_array_to_segments_s": host_s, "frames": n57, "utterances": 192, "segments": sum(len(r) for r in res),

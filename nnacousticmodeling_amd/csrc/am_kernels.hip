@@ -3087,9 +3087,9 @@ __global__ __launch_bounds__(256) void viterbi_fs_init_kernel(const ViterbiArgs 
     const int slot = blockIdx.y;
     const int ninf = __float_as_int(-1e20f);
     i32x4* pp = (i32x4*)a.pp + (size_t)slot * a.T;
-    int* t2 = a.tt + (size_t)slot * a.T;
+    unsigned short* t2 = (unsigned short*)a.tt + (size_t)slot * a.T;   // (frame-synchronous forms: entry times are 16-bit, like the two packed in the record)
     float* p = a.p + (size_t)slot * a.B;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.T; i += gridDim.x * 256) { pp[i] = (i32x4){ninf, ninf, ninf, 1 | (1 << 16)}; t2[i] = 1; }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.T; i += gridDim.x * 256) { pp[i] = (i32x4){ninf, ninf, ninf, 1 | (1 << 16)}; t2[i] = (unsigned short)1; }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.B; i += gridDim.x * 256) p[i] = a.p0[i];
     if (a.inv0_state && blockIdx.x == 0 && threadIdx.x == 0) {
         int* st = a.inv0_state + (size_t)slot * 16;   // parity 0: the state before frame 0
@@ -3108,7 +3108,7 @@ __global__ __launch_bounds__(256) void viterbi_fs_tri_kernel(const ViterbiArgs a
     if (n >= T) return;
     const long long row0 = a.offsets[a.slot_utt[slot]];
     i32x4* pp = (i32x4*)a.pp + (size_t)slot * T;
-    int* t2 = a.tt + (size_t)slot * T;
+    unsigned short* t2 = (unsigned short*)a.tt + (size_t)slot * T;
     float* pout = a.pout + (size_t)slot * T;
     const float* p = ((k & 1) ? a.p2 : a.p) + (size_t)slot * a.B;
     const float* lp1 = a.lp + (size_t)(row0 + k) * a.ldl;
@@ -3123,8 +3123,8 @@ __global__ __launch_bounds__(256) void viterbi_fs_tri_kernel(const ViterbiArgs a
     i32x4 nqa, nqb; int nta, ntb; float poa, pob;
     viterbi_tri_update(ga, ha, qa, ta, p, lp1, a.PIP, k, nqa, nta, poa);
     viterbi_tri_update(gb, hb, qb, tb, p, lp1, a.PIP, k, nqb, ntb, pob);
-    pp[n] = nqa; t2[n] = nta; pout[n] = poa;
-    if (two) { pp[m] = nqb; t2[m] = ntb; pout[m] = pob; }
+    pp[n] = nqa; t2[n] = (unsigned short)nta; pout[n] = poa;
+    if (two) { pp[m] = nqb; t2[m] = (unsigned short)ntb; pout[m] = pob; }
 }
 
 // The same update with the frame's log-posterior row and the slot's node scores staged in LDS.  Every triphone gathers four 4-B values (p[node],
@@ -3141,7 +3141,7 @@ __global__ __launch_bounds__(256) void viterbi_fs_tri_lds_kernel(const ViterbiAr
     const float* lp1 = a.lp + (size_t)(row0 + k) * a.ldl;
     const float* p = ((k & 1) ? a.p2 : a.p) + (size_t)slot * B;
     i32x4* pp = (i32x4*)a.pp + (size_t)slot * T;
-    int* t2 = a.tt + (size_t)slot * T;
+    unsigned short* t2 = (unsigned short*)a.tt + (size_t)slot * T;
     float* pout = a.pout + (size_t)slot * T;
     const i32x4* c0 = (const i32x4*)a.tri_idx;
     const f32x4* c1 = (const f32x4*)a.tri_self;
@@ -3174,8 +3174,8 @@ __global__ __launch_bounds__(256) void viterbi_fs_tri_lds_kernel(const ViterbiAr
             const i32x4 g = gb[it];
             viterbi_tri_apply(g, hb[it], qb[it], tb[it], s_p[g[0] & 0xffff], s_lp[(unsigned)g[0] >> 16], s_lp[g[1] & 0xffff], s_lp[(unsigned)g[1] >> 16], a.PIP, k, nqb, ntb, pob);
         }
-        pp[n] = nqa; t2[n] = nta; pout[n] = poa;
-        if (two) { pp[n + 256] = nqb; t2[n + 256] = ntb; pout[n + 256] = pob; }
+        pp[n] = nqa; t2[n] = (unsigned short)nta; pout[n] = poa;
+        if (two) { pp[n + 256] = nqb; t2[n + 256] = (unsigned short)ntb; pout[n + 256] = pob; }
     }
 }
 
@@ -3219,7 +3219,7 @@ __global__ __launch_bounds__(256) void viterbi_fs_node_kernel(const ViterbiArgs 
         const long long row = a.offsets[a.slot_utt[slot]] + k;
         ((k & 1) ? a.p : a.p2)[(size_t)slot * a.B + i] = mx + a.lm[i];
         a.bestI[(size_t)row * a.B + i] = mxi;
-        a.bestT[(size_t)row * a.B + i] = a.tt[(size_t)slot * a.T + mxi] - 1;
+        a.bestT[(size_t)row * a.B + i] = (int)((const unsigned short*)a.tt)[(size_t)slot * a.T + mxi] - 1;
     }
 }
 
@@ -3243,7 +3243,7 @@ __global__ __launch_bounds__(NTHR) void viterbi_fs_fused_kernel(const ViterbiArg
     const float* p = ((k & 1) ? a.p2 : a.p) + (size_t)slot * B;
     float* pnext = ((k & 1) ? a.p : a.p2) + (size_t)slot * B;
     i32x4* pp = (i32x4*)a.pp + (size_t)slot * T;
-    int* t2 = a.tt + (size_t)slot * T;
+    unsigned short* t2 = (unsigned short*)a.tt + (size_t)slot * T;
     const i32x4* c0 = (const i32x4*)a.tri_idx;
     const f32x4* c1 = (const f32x4*)a.tri_self;
     float* s_lp = vsm;
@@ -3257,7 +3257,7 @@ __global__ __launch_bounds__(NTHR) void viterbi_fs_fused_kernel(const ViterbiArg
         const int n0 = base + it * 2 * HALF;
         const int n = n0 < tri1 ? n0 : tri1 - 1, m = n0 + HALF < tri1 ? n0 + HALF : tri1 - 1;   // (past the block's end: repeats its last triphone's loads, stores nothing)
         ga[it] = c0[n]; gb[it] = c0[m]; ha[it] = c1[n]; hb[it] = c1[m];
-        qa[it] = __builtin_nontemporal_load(pp + n); qb[it] = __builtin_nontemporal_load(pp + m); ta[it] = __builtin_nontemporal_load(t2 + n); tb[it] = __builtin_nontemporal_load(t2 + m);
+        qa[it] = __builtin_nontemporal_load(pp + n); qb[it] = __builtin_nontemporal_load(pp + m); ta[it] = (int)__builtin_nontemporal_load(t2 + n); tb[it] = (int)__builtin_nontemporal_load(t2 + m);
     }
     // the list bounds and the language-model term of this thread's nodes (8 lanes per node, NTHR / 8 nodes per round): requested here, with everything
     // else, so that the node phase below does not start with a memory round trip of its own (the first two rounds; a block has ~54 nodes at the real size)
@@ -3286,8 +3286,8 @@ __global__ __launch_bounds__(NTHR) void viterbi_fs_fused_kernel(const ViterbiArg
             const i32x4 g = gb[it];
             viterbi_tri_apply(g, hb[it], qb[it], tb[it], s_p[g[0] & 0xffff], s_lp[(unsigned)g[0] >> 16], s_lp[g[1] & 0xffff], s_lp[(unsigned)g[1] >> 16], a.PIP, k, nqb, ntb, pob);
         }
-        __builtin_nontemporal_store(nqa, pp + n); __builtin_nontemporal_store(nta, t2 + n); s_po[n - tri0] = poa; s_t2[n - tri0] = nta;
-        if (two) { __builtin_nontemporal_store(nqb, pp + n + HALF); __builtin_nontemporal_store(ntb, t2 + n + HALF); s_po[n + HALF - tri0] = pob; s_t2[n + HALF - tri0] = ntb; }
+        __builtin_nontemporal_store(nqa, pp + n); __builtin_nontemporal_store((unsigned short)nta, t2 + n); s_po[n - tri0] = poa; s_t2[n - tri0] = nta;
+        if (two) { __builtin_nontemporal_store(nqb, pp + n + HALF); __builtin_nontemporal_store((unsigned short)ntb, t2 + n + HALF); s_po[n + HALF - tri0] = pob; s_t2[n + HALF - tri0] = ntb; }
         // the owner of the reference's triphone 0 leaves its state for the next frame's unreachable nodes
         if (n == a.inv0 || (two && n + HALF == a.inv0)) {
             const bool first = n == a.inv0;
