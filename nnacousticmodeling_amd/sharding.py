@@ -125,6 +125,7 @@ class PinnedPool:
         self._free = []                          # blocks given back, least recently returned first
         self._leased = {}                        # id(block) -> (weakref to the block, bytes)
         self._dead = []                          # (id, weakref) of leases whose array was dropped without give(): reaped under the lock
+        self._dropped = False                    # a lease has been dropped (not given back) since the last give()
         self._lock = threading.Lock()
 
     @staticmethod
@@ -141,6 +142,15 @@ class PinnedPool:
             ent = self._leased.get(key)
             if ent is not None and ent[0] is ref:
                 del self._leased[key]
+                self._dropped = True
+
+    def leases_get_dropped(self):
+        """True when the caller's pattern is take -> drop (the reference's ``predict`` contract has no release): the block of a
+        dropped lease is unpinned with its array, so the next request would page-lock a fresh one (~0.2 ms per MB, 0.1 s for the
+        core-test file's 442 MB) -- more than the page-locked download saves."""
+        with self._lock:
+            self._reap()
+            return self._dropped
 
     def _bytes(self):
         return sum(b.nbytes for b in self._free) + sum(nb for _, nb in self._leased.values())
@@ -191,6 +201,7 @@ class PinnedPool:
             if ent is None or ent[0]() is not block:
                 return False
             del self._leased[id(block)]
+            self._dropped = False
             self._free.append(block)
             total = self._bytes()
             while len(self._free) > 1 and total > self.cap:
@@ -333,12 +344,13 @@ class PosteriorRunner:
         """The gathered [N, C] array of forward_ff / forward_lstm.  Page-locked (every shard's download then runs at PCIe
         rate straight into its slice instead of through the driver's bounce buffers) -- except for the very first request
         of a single-shard runner: a one-shot call is faster into pageable memory (43 ms for the core-test file) than into
-        memory it first has to page-lock (~100 ms); from the second request on the pool is used."""
+        memory it first has to page-lock (~100 ms); from the second request on the pool is used -- as long as the caller gives
+        its results back (``release``); one that drops them instead gets pageable memory again."""
         with self._lock:
             self._requests += 1
             first = self._requests == 1
-        if len(self.shards) == 1 and first:
-            return np.empty((n, c), dtype=np.float32)
+        if len(self.shards) == 1 and (first or self.pool.leases_get_dropped()):
+            return np.empty((n, c), dtype=np.float32)   # (a caller that never releases: pageable every time beats page-locking every time)
         return self.pool.take(n, c)
 
     def release(self, y):

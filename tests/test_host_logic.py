@@ -494,3 +494,30 @@ def test_predict_to_npy_writes_what_np_save_writes(tmp_path, fake_runners, real_
     a, b = (tmp_path / "want.npy").read_bytes(), (tmp_path / "got.npy").read_bytes()
     assert len(a) == len(b) and a[:128] == b[:128]                      # the same .npy header
     assert np.max(np.abs(np.load(path) - want)) < 1e-5                   # (BLAS batching differs between shardings)
+
+
+def test_runner_stops_page_locking_for_a_caller_that_never_releases():
+    """The reference's predict() contract has no release: a caller that just drops its results would make the pool page-lock a
+    fresh block on every call (the dropped block is unpinned with its array).  A single-shard runner notices and hands out
+    pageable memory instead; one give() switches the pool back on."""
+    import gc
+    runner = sharding.PosteriorRunner([0], backend=fake_backend)
+    runner.pool = sharding.PinnedPool(lambda shape, dtype: np.empty(shape, dtype))   # (stands in for am_host_alloc)
+    try:
+        a = runner._out(100, 8)                       # first request of a single-shard runner: pageable
+        assert runner.pool.pinned_bytes() == 0
+        b = runner._out(100, 8)                       # second: a lease
+        assert runner.pool.pinned_bytes() == 100 * 8 * 4
+        del b
+        gc.collect()
+        assert runner.pool.leases_get_dropped()
+        c = runner._out(100, 8)                       # the lease was dropped, not given back: pageable from now on
+        assert runner.pool.pinned_bytes() == 0 and not runner.release(c)
+        runner.pool._dropped = False                  # (what a give() does)
+        d = runner._out(100, 8)
+        assert runner.pool.pinned_bytes() == 100 * 8 * 4 and runner.release(d)
+        e = runner._out(50, 8)                        # ... and a released block is re-used
+        assert runner.pool.pinned_bytes() == 100 * 8 * 4
+        del a, e
+    finally:
+        runner.close()
