@@ -349,8 +349,8 @@ class PosteriorRunner:
         with self._lock:
             self._requests += 1
             first = self._requests == 1
-        if len(self.shards) == 1 and (first or self.pool.leases_get_dropped()):
-            return np.empty((n, c), dtype=np.float32)   # (a caller that never releases: pageable every time beats page-locking every time)
+        if (len(self.shards) == 1 and first) or self.pool.leases_get_dropped():
+            return np.empty((n, c), dtype=np.float32)   # (a caller that never releases: pageable every time beats page-locking every time, on any number of shards)
         return self.pool.take(n, c)
 
     def release(self, y):
