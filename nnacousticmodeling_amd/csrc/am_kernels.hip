@@ -3379,7 +3379,8 @@ hipError_t launch_viterbi_fs_step(hipStream_t s, const ViterbiArgs& a, int k, in
     if (n_active <= 0) return hipSuccess;
     const char* sv = getenv("AM_VITERBI_LDS");       // (measurement: 0 = every launch on the form that gathers from global memory; 1 = staged, node maxima in their own launch)
     const size_t lds = ((size_t)a.ldl + (size_t)a.B) * sizeof(float);
-    if ((!sv || atoi(sv) > 1) && a.n_blk > 0 && a.perm && lds + 2 * 2048 * sizeof(float) <= 48 * 1024 && n_active >= 12) {
+    const char* fm = getenv("AM_VITERBI_FUSED_MIN");
+    if ((!sv || atoi(sv) > 1) && a.n_blk > 0 && a.perm && lds + 2 * 2048 * sizeof(float) <= 48 * 1024 && n_active >= (fm ? atoi(fm) : 1)) {   // (to the last utterance: 48.1 ms per real-size pass against 48.6 with the gathering form below 12 active ones)
         // 512 threads x 4 triphones: 50.8 ms per real-size pass; 256 x 8: 52.7; 1,024 x 2: 59.2 (AM_VITERBI_THREADS=256 for A/B timing)
         const char* tv = getenv("AM_VITERBI_THREADS");
         if (tv && atoi(tv) == 256) hipLaunchKernelGGL(viterbi_fs_fused_kernel<256>, dim3(a.n_blk, n_active), dim3(256), lds + 2 * 2048 * sizeof(float), s, a, k);
