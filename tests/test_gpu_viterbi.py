@@ -88,9 +88,9 @@ def test_larger_graphs_match_oracle(engine, P, S, PIP):
 
 @pytest.mark.parametrize("P,S", [(12, 300), (48, 1909)])
 def test_frame_sync_lds_form_matches_the_other_forms(engine, P, S, monkeypatch):
-    """With 12 or more active utterances the frame-synchronous form stages the frame's log-posterior row and the node scores in
-    LDS and takes the node maxima in the same launch (AM_VITERBI_LDS=1: in a launch of their own; 24 or more utterances: 2,048
-    triphones per staging, else 1,024); below 12, and with AM_VITERBI_LDS=0, it gathers from global memory.  40 utterances of 3..90 frames walk through all three; every form must give the oracle's segmentations
+    """The frame-synchronous form stages the frame's log-posterior row and the node scores in LDS and takes the node maxima in
+    the same launch (AM_VITERBI_LDS=1: in a launch of their own, from 12 active utterances on -- 24 or more: 2,048 triphones
+    per staging, else 1,024 --, below that gathering from global memory like AM_VITERBI_LDS=0).  40 utterances of 3..90 frames walk through all three; every form must give the oracle's segmentations
     (small graph) / the per-utterance kernel's (real-size graph: the oracle on a sample)."""
     from nnacousticmodeling_amd.phone_recog import PhoneRecog
     rng = np.random.default_rng(P * 7 + S)
