@@ -41,6 +41,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="skip the secondary split-f16 precision measurement")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary records (end to end, N=57,919, 6x2048+ivec, 3x512 LSTM)")
+    ap.add_argument("--allow-shared-gpu", action="store_true",
+                    help="let ranks share a physical GPU when the process sees fewer devices than ranks (rehearsals only; the record says so)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="time budget of the CPU baseline samples (all of them together)")
     return ap.parse_args()
 
@@ -76,6 +78,33 @@ def pmc_traffic(kernel_prefix="am::gemm_nt_f32_kernel"):
             tot += v["derived_hbm_bytes_per_launch"] * ln
             n += ln
     return (tot / n if n else None), os.path.relpath(files[-1], ROOT)
+
+
+def _host_cpu():
+    """(model name, physical cores, logical CPUs) of this host from /proc/cpuinfo (north_star: "core count stated")."""
+    model, cores, logical = None, set(), 0
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            key, _, val = line.partition(":")
+            key, val = key.strip(), val.strip()
+            if key == "processor":
+                logical += 1
+            elif key == "model name" and model is None:
+                model = val
+            elif key == "physical id":
+                phys = val
+            elif key == "core id":
+                core = val
+            elif not key and phys is not None and core is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return model, (len(cores) or None), (logical or os.cpu_count()), usable
 
 
 def _blas_threads():
@@ -125,7 +154,10 @@ def cpu_baseline(ft, params, layers, x, iv, seconds):
         by_threads[threads] = (d / t, d, t)
     best = max(by_threads, key=lambda c: by_threads[c][0])
     v, done, dt = by_threads[best]
+    cpu_model, phys_cores, logical_cpus, usable_cpus = _host_cpu()
     out = {"value": v, "unit": "frames/s", "cores": best, "kind": "port",
+           "host_cpu_model": cpu_model, "physical_cores": phys_cores, "logical_cpus": logical_cpus, "cpus_usable_by_this_process": usable_cpus,
+           "blas_threads_best": best,
            "sample": "first %d frames of the same synthetic file, 1024-frame batches as predict_folds.py:71-90 "
                      "(numpy/BLAS restatement of the Chainer CPU forward; Chainer itself is not installable here), %.1f s; "
                      "best of the BLAS thread counts tried" % (done, dt),
@@ -210,12 +242,24 @@ class _Guarded:
     """A secondary record that fails must not take the bench line (and the records behind it) down with it: the failure is recorded in its place."""
 
     def __init__(self, out, name):
-        self.out, self.name = out, name
+        self.out, self.name, self.owned = out, name, []
 
     def __enter__(self):
         return self
 
+    def own(self, obj):
+        """Device objects of this record (models, pipelines, decoders): closed when the block ends, however it ends -- a failed record
+        must not leave gigabytes of planes and member buffers allocated under the records behind it."""
+        self.owned.append(obj)
+        return obj
+
     def __exit__(self, etype, exc, tb):
+        for obj in reversed(self.owned):
+            try:
+                obj.close()
+            except Exception:
+                pass
+        self.owned = []
         if etype is not None and issubclass(etype, Exception):
             self.out[self.name] = {"error": "%s: %s" % (etype.__name__, exc)}
             return True
@@ -237,8 +281,8 @@ def secondary_records(eng, ft, params, layers, x, steps):
     off = make_offsets(np.random.default_rng(SEED + 3), 192, n57)   # 192 utterances of the core-test-like file (recurrent and decoder records)
     from nnacousticmodeling_amd.synthetic import make_gru_params, make_tdnn_params
     # (i) end to end: H2D of the frames, compute, D2H of the posteriors into page-locked memory (PCIe-inclusive; never `value`)
-    with _Guarded(out, "end_to_end"):
-        p = Pipeline(eng)
+    with _Guarded(out, "end_to_end") as g:
+        p = g.own(Pipeline(eng))
         p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
         p.set_members([m4])
         y = eng.pinned_empty((n_full, 1909))
@@ -253,7 +297,11 @@ def secondary_records(eng, ft, params, layers, x, steps):
                                      "(7.6 KB of posteriors per frame over PCIe; download of chunk c overlaps compute of chunk c+1)"}
         del y
     # (ii) the same network at the TIMIT core-test size (57,919 frames = 226.2 row tiles: partial last round of tiles)
-    with _Guarded(out, "n57919"):
+    with _Guarded(out, "n57919") as g:
+        g.own(m4)
+        p = g.own(Pipeline(eng))
+        p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
+        p.set_members([m4])
         p.ff_upload(x[:n57], None, n57, 0, 0)
         wall, _, prof = timed_runs(eng, p.ff_run, max(steps, 5), 2, pipe=p)
         k = max(steps, 5)
@@ -268,12 +316,12 @@ def secondary_records(eng, ft, params, layers, x, steps):
         p.close()
         m4.close()
     # (iii) BASELINE configs[2]: 6x2048 on 440 spliced + 100 i-vector columns
-    with _Guarded(out, "dnn_6x2048_ivec"):
+    with _Guarded(out, "dnn_6x2048_ivec") as g:
         rng = np.random.default_rng(SEED + 2)
         p6 = make_mlp_params(rng, 540, 2048, 6, 1909)
         iv = rng.standard_normal((n_full, 100)).astype(np.float32)
-        m6 = Model(eng, "ff", 6, p6)
-        p = Pipeline(eng)
+        m6 = g.own(Model(eng, "ff", 6, p6))
+        p = g.own(Pipeline(eng))
         p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"], 100)
         p.set_members([m6])
         p.ff_upload(x, iv, n_full, 0, 0)
@@ -286,11 +334,11 @@ def secondary_records(eng, ft, params, layers, x, steps):
         m6.close()
         del iv
     # (iv) BASELINE configs[3]: 3x512 LSTM (uni-directional: the reference has no bidirectional net), 192 utterances
-    with _Guarded(out, "lstm_3x512"):
+    with _Guarded(out, "lstm_3x512") as g:
         rng = np.random.default_rng(SEED + 3)
         make_offsets(rng, 192, n57)   # (advances rng exactly as before: the same weights as earlier rounds)
-        ml = Model(eng, "lstm", 3, make_lstm_params(rng, 40, 512, 3, 1909))
-        p = Pipeline(eng)
+        ml = g.own(Model(eng, "lstm", 3, make_lstm_params(rng, 40, 512, 3, 1909)))
+        p = g.own(Pipeline(eng))
         p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
         p.set_members([ml])
         p.lstm_upload(x[:n57], None, off, 0)
@@ -311,10 +359,10 @@ def secondary_records(eng, ft, params, layers, x, steps):
         ml.close()
     # (iv b) the reference's own recurrent recipe shape (scripts/papers/specom2018/run.sh:9: "-n lstm -l 4 -u 1024 --timedelay 5"): its weights do not fit
     # the register file, so it runs on the per-step kernels (one launch per (layer, time) diagonal)
-    with _Guarded(out, "lstm_4x1024_td5"):
+    with _Guarded(out, "lstm_4x1024_td5") as g:
         rng = np.random.default_rng(SEED + 6)
-        ml4 = Model(eng, "lstm", 4, make_lstm_params(rng, 40, 1024, 4, 1909))
-        p = Pipeline(eng)
+        ml4 = g.own(Model(eng, "lstm", 4, make_lstm_params(rng, 40, 1024, 4, 1909)))
+        p = g.own(Pipeline(eng))
         p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
         p.set_members([ml4])
         p.lstm_upload(x[:n57], None, off, 5)
@@ -330,10 +378,10 @@ def secondary_records(eng, ft, params, layers, x, steps):
         ml4.close()
     # (v) BASELINE configs[4]: 10 fold members (4x1024 each), logits averaged on the device (evaluate.py:35-51) -- one GPU's share;
     # on a node the folds x utterances shard over the GPUs with no collective (sharding.py)
-    with _Guarded(out, "ensemble_10x4x1024"):
+    with _Guarded(out, "ensemble_10x4x1024") as g:
         rng = np.random.default_rng(SEED + 4)
-        members = [Model(eng, "ff", layers, make_mlp_params(rng, 440, 1024, layers, 1909)) for _ in range(10)]
-        p = Pipeline(eng)
+        members = [g.own(Model(eng, "ff", layers, make_mlp_params(rng, 440, 1024, layers, 1909))) for _ in range(10)]
+        p = g.own(Pipeline(eng))
         p.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"])
         p.set_members(members)
         p.ff_upload(x[:n57], None, n57, 0, 0)
@@ -350,10 +398,10 @@ def secondary_records(eng, ft, params, layers, x, steps):
         for m_ in members:
             m_.close()
     # (vi) row n4: the GRU stack at the recurrent config's size (chainer L.GRU: two dependent products per step)
-    with _Guarded(out, "gru_3x512"):
+    with _Guarded(out, "gru_3x512") as g:
         rng = np.random.default_rng(SEED + 5)
-        mg = Model(eng, "gru", 3, make_gru_params(rng, 40, 512, 3, 1909, reset_gate=True))
-        p = Pipeline(eng)
+        mg = g.own(Model(eng, "gru", 3, make_gru_params(rng, 40, 512, 3, 1909, reset_gate=True)))
+        p = g.own(Pipeline(eng))
         p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
         p.set_members([mg])
         p.lstm_upload(x[:n57], None, off, 0)
@@ -368,12 +416,13 @@ def secondary_records(eng, ft, params, layers, x, steps):
         p.close()
         mg.close()
     # (vii) row n4: TDNN 5-5-5-5 x 1024 (scripts/papers/tsd2018/run.sh:22-30): every (1, k) convolution as one MFMA GEMM with windowed rows
-    with _Guarded(out, "tdnn_5555x1024"):
+    with _Guarded(out, "tdnn_5555x1024") as g:
         from nnacousticmodeling_amd.kaldi_ft import tdnn_splice, tile_centre_frame
+        rng = np.random.default_rng(SEED + 7)   # its own stream: the weights do not depend on which records ran (or failed) before
         ksize, units = [5, 5, 5, 5], [1024] * 4
         tft = tile_centre_frame(loadKaldiFeatureTransform(os.path.join(golden, "final.feature_transform")), tdnn_splice(ksize))
-        mt = Model(eng, "tdnn", 4, make_tdnn_params(rng, 40, units, ksize, 1909))
-        p = Pipeline(eng)
+        mt = g.own(Model(eng, "tdnn", 4, make_tdnn_params(rng, 40, units, ksize, 1909)))
+        p = g.own(Pipeline(eng))
         p.set_frontend(40, tft["shifts"], tft["addShift"], tft["rescale"])
         p.set_members([mt])
         p.ff_upload(x[:n57], None, n57, 0, 0)
@@ -393,7 +442,7 @@ def secondary_records(eng, ft, params, layers, x, steps):
         mt.close()
     # (viii) row n1: the frame-synchronous Viterbi decoder on a synthetic graph of the real image's size (48 phones, 2,304 nodes,
     # ~88k triphones, 1909 states; the inputs tests/golden/make_viterbi_fullsize_golden.py describes), 192 utterances / 57,919 frames
-    with _Guarded(out, "viterbi_realsize"):
+    with _Guarded(out, "viterbi_realsize") as g:
         from nnacousticmodeling_amd.phone_recog import PhoneRecog
         from nnacousticmodeling_amd.synthetic import make_graph
         rng = np.random.default_rng(481909)
@@ -403,12 +452,12 @@ def secondary_records(eng, ft, params, layers, x, steps):
         z *= 2.0
         mx = z.max(axis=1, keepdims=True)
         z -= mx + np.log(np.exp(z - mx).sum(axis=1, keepdims=True))
-        dec = PhoneRecog(eng, dict(graph, numPhones=48, numBiphones=B_, numTriphones=T_), -20.0, 1.0)
+        dec = g.own(PhoneRecog(eng, dict(graph, numPhones=48, numBiphones=B_, numTriphones=T_), -20.0, 1.0))
         dec.recognise(z[:off[4]], off[:5])
         t0 = time.perf_counter()
         res = dec.recognise(z, off)
         host_s = time.perf_counter() - t0
-        pass_ms = eng.elapsed_ms(62, 63)   # device time of the un-instrumented pass: first launch -> last launch done (am_decode_* records both)
+        pass_ms = eng.decode_elapsed_ms()   # device time of the un-instrumented pass: first launch -> last launch done (am_decode_* records both)
         eng.profile(True)
         eng.profile_reset()
         dec.recognise(z, off)
@@ -428,6 +477,28 @@ def secondary_records(eng, ft, params, layers, x, steps):
                                                 "achieved": vit_bytes / (vit_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": vit_bytes / (vit_ms * 1e-3) / 8e12,
                                                 "algorithmic_bytes": vit_bytes,
                                                 "measured": "one HIP event pair around the pass's launch sequence on the engine's compute stream"}}
+        # CPU leg of this record: the reference's own decoder built from source (oracle/_ref, checker use only), ONE thread as the
+        # shipped binary, on a bounded sample of the same utterances; also checks the GPU segmentations on that sample
+        from oracle import viterbi_oracle as vo
+        if vo.reference_available():
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                img = os.path.join(td, "g.img")
+                vo.write_image(img, graph)
+                ku = 1
+                while ku < 192 and off[ku] < 6000:
+                    ku += 1
+                sample = [z[off[u]:off[u + 1]] for u in range(ku)]
+                t0 = time.perf_counter()
+                ref = vo.reference_recog(img, sample, -20.0, 1.0)
+                cpu_s = time.perf_counter() - t0
+            cpu_model, phys_cores, _, _ = _host_cpu()
+            out["viterbi_realsize"]["cpu_baseline"] = {"value": float(off[ku]) / cpu_s, "unit": "frames/s", "cores": 1, "kind": "reference",
+                                                       "sample": "the first %d utterances (%d frames) of the same file through recog_src/source/phone_recog.cpp built by oracle/Makefile, %.1f s" % (ku, int(off[ku]), cpu_s),
+                                                       "host_cpu_model": cpu_model, "physical_cores": phys_cores,
+                                                       "segmentations_identical_on_sample": bool(all(ref[u] == res[u] for u in range(ku)))}
+        else:
+            out["viterbi_realsize"]["cpu_baseline"] = {"skipped": "oracle/_ref/libphonerecog_ref.so not present (built by __graft_entry__.build() where /root/reference exists)"}
         dec.close()
         del z
     return out
@@ -474,14 +545,22 @@ def product_host_to_host(n_devices, ft, params, layers, x):
 
 def main():
     args = parse_args()
-    from nnacousticmodeling_amd.dist_util import Ranks
+    from bench_ranks import Ranks
     from nnacousticmodeling_amd.engine import Engine, Model, Pipeline
     ranks = Ranks()  # RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env; gloo for barrier + max-over-ranks only
     rank, local_rank, n_gpus = ranks.rank, ranks.local_rank, ranks.world
 
     ft, params, layers, x, iv, d_iv = make_workload(args.model, args.frames, rank)
-    from nnacousticmodeling_amd.engine import device_count
-    eng = Engine(local_rank % max(device_count(), 1))  # one rank per GPU; wraps only when ranks outnumber the visible GPUs
+    from nnacousticmodeling_amd.engine import device_count, device_pci_bus_id
+    n_dev = device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py: no HIP device visible (there is no CPU fallback)")
+    if local_rank >= n_dev and not args.allow_shared_gpu:
+        # a run that silently put two ranks on one card would print "n_gpus": N for fewer than N GPUs' worth of work
+        raise SystemExit("bench.py: local rank %d but only %d GPU(s) visible; one rank per GPU (--allow-shared-gpu to rehearse on fewer cards)" % (local_rank, n_dev))
+    dev = local_rank % n_dev
+    bus_ids = ranks.gather_objects(device_pci_bus_id(dev))   # which physical card every rank really drives
+    eng = Engine(dev)
     pipe = Pipeline(eng)
     pipe.set_frontend(40, ft["shifts"], ft["addShift"], ft["rescale"], d_iv)
     pipe.set_members([Model(eng, "ff", layers, params)])
@@ -543,6 +622,7 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (N(0,1) fbank-like frames, random-init weights, real final.feature_transform)",
+            "devices": sorted(set(bus_ids)), "ranks_per_device": {b: bus_ids.count(b) for b in sorted(set(bus_ids))},
             "config": {"workload": "%s DNN 440->%s->1909, %d frames per GPU per step (BASELINE.json configs[1], 192 x 1024 frames), "
                                    "splice+transform+forward+log-softmax device-resident" % (args.model, args.model, args.frames),
                        "frames_per_gpu": args.frames, "parallelism": "frame shards, no collective"},
@@ -552,7 +632,11 @@ def main():
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if achieved else None, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC, %s)" % traffic_src if traffic else None,
-                         "algorithmic_bytes_per_launch": (args.frames * 4 * (440 + 4 * 1024 + 4 * 1024 + 1909) + 4 * (440 * 1024 + 3 * 1024 * 1024 + 1024 * 1909)) / float(max(launches_per_step, 1)) if args.model == "4x1024" else None,
+                         # a fused chain must move 160 B in + 7,636 B out per frame (+ the weights once); the traffic above that is
+                         # hidden activations materialised between the layers (written once, read once) and A panels re-fetched per XCD.  At
+                         # ~0.87 TB/s the launch is nowhere near the HBM bound: the fraction that matters is `frac` (MFMA).
+                         "algorithmic_bytes_per_launch": (args.frames * (160 + 7636) + 4 * (440 * 1024 + 3 * 1024 * 1024 + 1024 * 1909)) / float(max(launches_per_step, 1)) if args.model == "4x1024" else None,
+                         "materialised_activation_bytes_per_launch": (args.frames * 4 * (440 + 4 * 1024 + 4 * 1024 + 1909) + 4 * (440 * 1024 + 3 * 1024 * 1024 + 1024 * 1909)) / float(max(launches_per_step, 1)) if args.model == "4x1024" else None,
                          "avg_launch_ms": gemm_ms / gemm_calls if gemm_calls else None,
                          "measured": "HIP events around every launch on the engine's compute stream, in a second loop of the same K steps (the headline loop carries no events)"},
             "kernels_ms_per_step": {k: v[1] / args.steps for k, v in prof.items()},

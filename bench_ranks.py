@@ -1,4 +1,4 @@
-"""One-process-per-GPU plumbing (bench.py, multi-process launches): rank discovery, barrier, max-over-ranks and the
+"""One-process-per-GPU plumbing of bench.py and tests/dist_worker.py (not part of the product package, which imports no torch): rank discovery, barrier, max-over-ranks and the
 host-side gather of per-rank posterior shards.  The data path itself needs no collective (frames / utterances shard
 embarrassingly); ``torch.distributed`` (gloo, CPU tensors) is used only for these control-plane steps.
 """
@@ -32,6 +32,14 @@ class Ranks:
         t = torch.tensor([float(value)], dtype=torch.float64)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
         return float(t.item())
+
+    def gather_objects(self, obj):
+        """Every rank's object, in rank order, on every rank."""
+        if self._dist is None:
+            return [obj]
+        got = [None] * self.world
+        self._dist.all_gather_object(got, obj)
+        return got
 
     def gather_rows(self, local, n_total):
         """Host-side gather of contiguous row shards (rank order = row order) into one array on rank 0."""

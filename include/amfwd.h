@@ -46,6 +46,9 @@ enum {
 
 /* ---- discovery / errors ------------------------------------------------------------------------- */
 int am_device_count(void);            /* number of visible HIP devices, 0 if none (never negative) */
+/* PCI bus id ("0000:c1:00.0") of a visible device: two ranks that were handed the same physical card (predict_folds.py:158-161 /
+ * evaluate.py's --gpu names a card by index only) can tell.  buflen >= 16.  No engine needed. */
+int am_device_pci_bus_id(int device, char* buf, int buflen);
 const char* am_last_error(void);      /* thread-local, never NULL                                   */
 const char* am_version(void);
 
@@ -73,8 +76,11 @@ int am_pipeline_overflowed(am_pipeline* p, int* flag);   /* synchronises; flag =
 
 /* HIP events on the engine's compute stream (the stream every kernel below is launched on).
  * slot in [0, 64).  Used by bench.py for the timed region. */
-int am_event_record(am_engine* e, int slot);   /* (slots 62 and 63 are recorded by am_decode_* around its launch sequence) */
+int am_event_record(am_engine* e, int slot);
 int am_event_elapsed_ms(am_engine* e, int slot_start, int slot_stop, float* ms); /* synchronises on slot_stop */
+/* Device time of the launch sequence of this engine's most recent am_decode_host / am_decode_pipeline call (first launch -> last
+ * launch done, gaps included; two events of the engine's own, no caller slot is touched).  Synchronises on the second event. */
+int am_decode_elapsed_ms(am_engine* e, float* ms);
 
 /* Per-kernel timing: when on, every kernel launch is bracketed by a HIP event pair on the compute stream.
  * am_profile_read synchronises and returns, per kernel id, the number of launches and the summed duration

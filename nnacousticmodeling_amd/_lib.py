@@ -27,6 +27,7 @@ c_void_pp = C.POINTER(C.c_void_p)
 # name -> (restype, argtypes); every symbol declared in include/amfwd.h
 SIGNATURES = {
     "am_device_count": (C.c_int, []),
+    "am_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "am_last_error": (C.c_char_p, []),
     "am_version": (C.c_char_p, []),
     "am_engine_create": (C.c_int, [C.c_int, c_void_pp]),
@@ -37,6 +38,7 @@ SIGNATURES = {
     "am_pipeline_overflowed": (C.c_int, [C.c_void_p, c_int_p]),
     "am_event_record": (C.c_int, [C.c_void_p, C.c_int]),
     "am_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p]),
+    "am_decode_elapsed_ms": (C.c_int, [C.c_void_p, c_float_p]),
     "am_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "am_profile_reset": (C.c_int, [C.c_void_p]),
     "am_profile_read": (C.c_int, [C.c_void_p, c_int64_p, C.POINTER(C.c_double)]),

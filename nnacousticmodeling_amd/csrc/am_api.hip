@@ -81,6 +81,7 @@ struct am_engine {
     int precision = AM_PRECISION_F32;  // AM_PRECISION_* for the feed-forward Linear layers
     DevBuf d_overflow;                 // int flag raised by split-f16 kernels when an activation does not fit f16
     hipEvent_t ev[64] = {};
+    hipEvent_t dec_ev[2] = {nullptr, nullptr};   // around the launch sequence of this engine's last am_decode_* call (am_decode_elapsed_ms)
     bool profile = false;
     struct Rec { int id; hipEvent_t a, b; };
     std::vector<Rec> recs;
@@ -383,6 +384,7 @@ static void engine_teardown(am_engine* e)
     for (auto& r : e->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     for (auto ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto ev : e->dec_ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& s : e->scratch) s.release();
     e->d_overflow.release();
     (void)hipStreamDestroy(e->stream);
@@ -419,6 +421,25 @@ extern "C" int am_event_elapsed_ms(am_engine* e, int a, int b, float* ms)
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipEventSynchronize(e->ev[b]));
     HIP_TRY(hipEventElapsedTime(ms, e->ev[a], e->ev[b]));
+    return AM_OK;
+}
+
+extern "C" int am_decode_elapsed_ms(am_engine* e, float* ms)
+{
+    if (!e || !ms) return fail(AM_EINVAL, "am_decode_elapsed_ms: bad argument");
+    if (!e->dec_ev[0] || !e->dec_ev[1]) return fail(AM_EINVAL, "am_decode_elapsed_ms: no am_decode_* call has run on this engine");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventSynchronize(e->dec_ev[1]));
+    HIP_TRY(hipEventElapsedTime(ms, e->dec_ev[0], e->dec_ev[1]));
+    return AM_OK;
+}
+
+extern "C" int am_device_pci_bus_id(int device, char* buf, int buflen)
+{
+    if (!buf || buflen < 16) return fail(AM_EINVAL, "am_device_pci_bus_id: the buffer must hold at least 16 bytes");
+    const int n = am_device_count();
+    if (device < 0 || device >= n) return fail(AM_ENODEV, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipDeviceGetPCIBusId(buf, buflen, device));
     return AM_OK;
 }
 
@@ -1673,6 +1694,10 @@ extern "C" int am_lstm_run(am_pipeline* p)
     HIP_TRY(hipSetDevice(e->device));
     p->results_valid = true;   // (cleared again below if the enqueue fails)
     if (p->n_packed == 0) return AM_OK;
+    // a give-up on this device is sticky for EVERY pipeline, also those that planned the persistent form before it happened (another
+    // engine or shard on the same card): they drop their plan here instead of each paying its own 2-s stall
+    if (gate_of(e).off.load())
+        for (auto& pl : p->persist) if (pl.form == 1) pl.release();
     auto eager = [&] { const int rc = lstm_enqueue(p); if (rc != AM_OK) p->results_valid = false; return rc; };
     // with the persistent form a pass is a handful of launches on two streams: nothing to gain from a graph, and a replayed
     // graph serialises the second stream's branch (measured: 10.2 ms replayed against 8.8 ms eager)
@@ -2261,10 +2286,10 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
     a.seg_begin = d->seg_begin.as<int>(); a.seg_end = d->seg_end.as<int>(); a.seg_tri = d->seg_tri.as<int>(); a.seg_count = d->seg_count.as<int>();
     static const int64_t fs_env = env_int("AM_VITERBI_FS", 1);
     const bool fs_ok = d->form == AM_VITERBI_AUTO ? fs_env != 0 : d->form == AM_VITERBI_FRAME_SYNC;
-    // event slots 62 / 63 bracket the decode's launch sequence (am_event_elapsed_ms(e, 62, 63): device time of the whole pass,
-    // launch gaps included, without the cost of an event pair per launch)
-    for (int sl : {62, 63}) if (!e->ev[sl]) HIP_TRY(hipEventCreate(&e->ev[sl]));
-    HIP_TRY(hipEventRecord(e->ev[62], e->stream));
+    // two events of the engine's own bracket the decode's launch sequence (am_decode_elapsed_ms: device time of the whole pass, launch
+    // gaps included, without the cost of an event pair per launch); the caller's am_event_record slots are never touched
+    for (hipEvent_t& ev : e->dec_ev) if (!ev) HIP_TRY(hipEventCreate(&ev));
+    HIP_TRY(hipEventRecord(e->dec_ev[0], e->stream));
     const auto host_t0 = std::chrono::steady_clock::now();
     if (a.compact && fs_ok && fs_fits) {
         // frame-synchronous: slots = utterances by length (longest first); step k advances the first n_active slots
@@ -2277,7 +2302,13 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
         // enqueues the ~1,280 launches in 3 ms, the boundaries are not the cost)
         int rc = run_kernel(e, K_VITERBI, [&] { return launch_viterbi_fs_init(e->stream, a, n_utts); });
         int active = n_utts;
-        std::vector<hipEvent_t> seg_ev;                       // diagnostic (AM_VITERBI_TIMING=2): device time per 64 frames
+        struct SegEvents {                                    // diagnostic (AM_VITERBI_TIMING=2): device time per 64 frames
+            std::vector<hipEvent_t> v;
+            ~SegEvents() { for (hipEvent_t ev : v) (void)hipEventDestroy(ev); }   // also on the early returns below
+            void push_back(hipEvent_t ev) { v.push_back(ev); }
+            size_t size() const { return v.size(); }
+            hipEvent_t operator[](size_t i) const { return v[i]; }
+        } seg_ev;
         std::vector<int> seg_active;
         const bool seg_timing = env_int("AM_VITERBI_TIMING", 0) == 2;
         for (int64_t k = 0; k < longest && rc == AM_OK; ++k) {
@@ -2293,13 +2324,12 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
                 const int64_t nf = std::min<int64_t>(64, longest - (int64_t)i * 64);
                 fprintf(stderr, "libamfwd: frames %4zu..: %3d active at the start, %.3f ms, %.1f us per frame\n", i * 64, seg_active[i], ms, ms * 1e3 / nf);
             }
-            for (hipEvent_t ev2 : seg_ev) (void)hipEventDestroy(ev2);
         }
         if (rc == AM_OK) rc = run_kernel(e, K_VITERBI, [&] { return launch_viterbi_fs_trace(e->stream, a, n_utts); });
         AM_TRY(rc);
     } else
     AM_TRY(run_kernel(e, K_VITERBI, [&] { return launch_viterbi(e->stream, a, n_utts); }));
-    HIP_TRY(hipEventRecord(e->ev[63], e->stream));
+    HIP_TRY(hipEventRecord(e->dec_ev[1], e->stream));
     if (env_int("AM_VITERBI_TIMING", 0) != 0)   // diagnostic: how long the host took to enqueue the launch sequence
         fprintf(stderr, "libamfwd: decode launch sequence enqueued in %.3f ms (host)\n",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count());

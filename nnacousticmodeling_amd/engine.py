@@ -28,6 +28,13 @@ def device_count():
     return int(_lib.load().am_device_count())
 
 
+def device_pci_bus_id(device):
+    """PCI bus id of a visible device ("0000:c1:00.0"): identifies the physical card behind a device index."""
+    buf = C.create_string_buffer(64)
+    check(_lib.load().am_device_pci_bus_id(int(device), buf, 64))
+    return buf.value.decode()
+
+
 class _Pinned:
     """Owner of one am_host_alloc block, exported through the array interface (numpy keeps it alive as .base)."""
 
@@ -89,6 +96,12 @@ class Engine:
     def elapsed_ms(self, a, b):
         ms = C.c_float()
         check(self._lib.am_event_elapsed_ms(self._h, int(a), int(b), C.byref(ms)))
+        return float(ms.value)
+
+    def decode_elapsed_ms(self):
+        """Device time of the launch sequence of this engine's last decode (PhoneRecog.recognise / recognise_pipeline)."""
+        ms = C.c_float()
+        check(self._lib.am_decode_elapsed_ms(self._h, C.byref(ms)))
         return float(ms.value)
 
     def set_precision(self, mode):

@@ -125,7 +125,8 @@ class PinnedPool:
         self._free = []                          # blocks given back, least recently returned first
         self._leased = {}                        # id(block) -> (weakref to the block, bytes)
         self._dead = []                          # (id, weakref) of leases whose array was dropped without give(): reaped under the lock
-        self._dropped = False                    # a lease has been dropped (not given back) since the last give()
+        self._dropped = False                    # a lease has been dropped (not given back) since the caller's last give()
+        self._pending = 0                        # bytes reserved by take() calls that are page-locking their block right now
         self._lock = threading.Lock()
 
     @staticmethod
@@ -153,7 +154,7 @@ class PinnedPool:
             return self._dropped
 
     def _bytes(self):
-        return sum(b.nbytes for b in self._free) + sum(nb for _, nb in self._leased.values())
+        return sum(b.nbytes for b in self._free) + sum(nb for _, nb in self._leased.values()) + self._pending
 
     def pinned_bytes(self):
         with self._lock:
@@ -176,6 +177,7 @@ class PinnedPool:
                     best = i
             if best is not None:
                 block = self._free.pop(best)
+                reserved = block.nbytes              # (out of _free, not yet in _leased: still counted)
             else:
                 used = self._bytes()
                 while self._free and used + 4 * need > self.cap:
@@ -183,17 +185,28 @@ class PinnedPool:
                 if used + 4 * need > self.cap:
                     return np.empty((n, c), dtype=np.float32)   # over the cap: pageable memory
                 block = None
+                reserved = 4 * need                  # N shard threads asking at once each see the others' reservations
+            self._pending += reserved
         if block is None:
-            block = self._alloc((need,), np.float32)            # (outside the lock: page-locking takes ~0.2 ms per MB)
+            try:
+                block = self._alloc((need,), np.float32)        # (outside the lock: page-locking takes ~0.2 ms per MB)
+            except Exception:                                   # the host would not page-lock more: pageable, never an error in a shard thread
+                with self._lock:
+                    self._pending -= reserved
+                return np.empty((n, c), dtype=np.float32)
         key = id(block)
         ref = weakref.ref(block, lambda r, k=key: self._dead.append((k, r)))
         with self._lock:
+            self._pending -= reserved
             self._leased[key] = (ref, block.nbytes)
         return block[:need].reshape(n, c)
 
-    def give(self, y):
+    def give(self, y, from_caller=False):
         """Return a leased array's block to the pool.  Arrays that are not leases of this pool (pageable ones, slices of
-        somebody else's memory) are ignored.  The caller must not touch ``y`` (or views of it) afterwards."""
+        somebody else's memory) are ignored.  The caller must not touch ``y`` (or views of it) afterwards.
+        ``from_caller``: the array is a RESULT the runner's caller hands back (``PosteriorRunner.release``) -- only that says the
+        caller's pattern is take -> give and switches the pool back on after dropped leases; the runner's own per-shard
+        temporaries come back through here too and must not."""
         block = self._root(y)
         with self._lock:
             self._reap()
@@ -201,7 +214,8 @@ class PinnedPool:
             if ent is None or ent[0]() is not block:
                 return False
             del self._leased[id(block)]
-            self._dropped = False
+            if from_caller:
+                self._dropped = False
             self._free.append(block)
             total = self._bytes()
             while len(self._free) > 1 and total > self.cap:
@@ -355,7 +369,7 @@ class PosteriorRunner:
 
     def release(self, y):
         """Offer a result array back to the pool (no-op for pageable arrays).  ``y`` must not be used afterwards."""
-        return self.pool.give(y)
+        return self.pool.give(y, from_caller=True)
 
     def _configure(self, st, ensemble, D, shifts, ft, d_iv, prior, combine, normalise):
         specs = list(ensemble.members())
@@ -427,8 +441,9 @@ class PosteriorRunner:
         offsets = check_offsets(offsets, n)   # every row then belongs to an utterance of some bin: all of y is overwritten
         iv = None if ivectors is None else np.ascontiguousarray(ivectors, dtype=np.float32)
         d_iv = 0 if iv is None else iv.shape[1]
-        y = self._out(n, ens.num_classes)
         bins = lstm_bins(offsets, len(self.shards))
+        # several bins: y is only ever written by the host copies below (never by DMA), so page-locking it buys nothing
+        y = self._out(n, ens.num_classes) if len(bins) == 1 else np.empty((n, ens.num_classes), dtype=np.float32)
         jobs = []
         for utts, shard in zip(bins, self.shards):
             def job(utts=utts, shard=shard):

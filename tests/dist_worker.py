@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from nnacousticmodeling_amd import networks, sharding  # noqa: E402
-from nnacousticmodeling_amd.dist_util import Ranks  # noqa: E402
+from bench_ranks import Ranks  # noqa: E402
 from oracle import am_oracle as orc  # noqa: E402
 from tests import fake_backend  # noqa: E402
 

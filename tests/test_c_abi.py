@@ -61,3 +61,14 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("self-oracle", ""), "%s mentions the oracle" % f
+
+
+def test_product_package_imports_no_torch():
+    """north_star: host code is Python over a C ABI, "no PyTorch".  torch.distributed serves bench.py's barrier only and lives
+    beside it (bench_ranks.py), outside the package."""
+    import re
+    pkg = os.path.join(ROOT, "nnacousticmodeling_amd")
+    for name in sorted(os.listdir(pkg)):
+        if name.endswith(".py"):
+            src = open(os.path.join(pkg, name)).read()
+            assert not re.search(r"^\s*(import|from)\s+(torch|chainer|triton)\b", src, re.M), name

@@ -152,6 +152,9 @@ def test_persistent_kernel_gives_up_and_falls_back(engine, real_ft_path, monkeyp
     x = rng.standard_normal((2400, 40)).astype(np.float32)
     p = _pipe(engine, "lstm", 2, params, ft, [0])
     good = p.forward_lstm(x, off)
+    p2 = _pipe(engine, "lstm", 2, params, ft, [0])      # a second pipeline that planned the persistent form BEFORE the give-up
+    p2.lstm_upload(x, None, off, 0)
+    assert p2.recurrent_form() == (1, 1)
     monkeypatch.setenv("AM_LSTM_TEST_TIMEOUT", "1")
     t0 = time.perf_counter()
     got = p.forward_lstm(x, off)
@@ -166,6 +169,12 @@ def test_persistent_kernel_gives_up_and_falls_back(engine, real_ft_path, monkeyp
     t0 = time.perf_counter()
     assert np.array_equal(p.forward_lstm(x, off), good)
     assert time.perf_counter() - t0 < 1.0 and p.recurrent_form() == (0, 1)
+    # ... and for every pipeline of the device, also one whose upload predates the give-up: it drops its plan at its next run
+    t0 = time.perf_counter()
+    p2.lstm_run()
+    assert np.array_equal(p2.lstm_download(), good)
+    assert time.perf_counter() - t0 < 1.0 and p2.recurrent_form() == (0, 1)
+    p2.close()
     _lib.check(lib.am_lstm_persist_reenable(0))
     assert lib.am_lstm_persist_enabled(0) == 1
     assert np.array_equal(p.forward_lstm(x, off), good) and p.recurrent_form() == (1, 1)   # back on the persistent kernel

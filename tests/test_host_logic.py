@@ -513,7 +513,7 @@ def test_runner_stops_page_locking_for_a_caller_that_never_releases():
         assert runner.pool.leases_get_dropped()
         c = runner._out(100, 8)                       # the lease was dropped, not given back: pageable from now on
         assert runner.pool.pinned_bytes() == 0 and not runner.release(c)
-        runner.pool._dropped = False                  # (what a give() does)
+        runner.pool._dropped = False                  # (what a release() of a result does)
         d = runner._out(100, 8)
         assert runner.pool.pinned_bytes() == 100 * 8 * 4 and runner.release(d)
         e = runner._out(50, 8)                        # ... and a released block is re-used
@@ -521,3 +521,69 @@ def test_runner_stops_page_locking_for_a_caller_that_never_releases():
         del a, e
     finally:
         runner.close()
+
+
+def test_multi_shard_recurrent_predict_with_dropped_results_stops_allocating(real_ft_path):
+    """the runner's own per-shard temporaries (forward_lstm's `ys`) come back through give() as well; they must not
+    clear the dropped-lease latch, or a caller that drops its results (the reference's predict() contract) makes the pool
+    alternate between pageable and freshly page-locked result arrays.  After warm-up: no allocation at all, call after call."""
+    import gc
+    rng = np.random.default_rng(9)
+    ft = orc.centre_frame_transform(orc.load_kaldi_feature_transform(real_ft_path))
+    params = orc.make_lstm_params(rng, 40, 16, 2, 39)
+    off = orc.make_offsets(rng, 9, 120, lo=4, hi=30)
+    x = rng.standard_normal((120, 40)).astype(np.float32)
+    spec = networks.get_nn("lstm", 2, [16], 39).set_params(params)
+    runner = sharding.PosteriorRunner(range(3), backend=fake_backend)
+    allocs = []
+
+    def alloc(shape, dtype):
+        allocs.append(int(np.prod(shape)))
+        return np.empty(shape, dtype)
+    runner.pool = sharding.PinnedPool(alloc)
+    try:
+        want = orc.predict(orc.LSTM(params, 2), x, off, True, 1, 0, ft)
+        seen = []
+        for _ in range(6):
+            y = runner.forward_lstm(spec, x, off, ft=ft)
+            assert np.max(np.abs(y - want)) < 1e-5
+            del y                                       # the caller DROPS its result (no release)
+            gc.collect()
+            seen.append(len(allocs))
+        assert seen[1:] == [seen[1]] * 5, seen      # the three per-shard blocks of the first call(s), then none
+        assert max(allocs) < 120 * 39               # and never a block of the whole file's size: the gathered array is pageable
+    finally:
+        runner.close()
+
+
+def test_pinned_pool_reserves_bytes_while_a_block_is_being_page_locked():
+    """N shard threads asking at once must not all see `used + need <= cap`; and a failing allocator gives pageable memory."""
+    import threading
+    gate, started = threading.Event(), threading.Barrier(5)
+
+    def slow_alloc(shape, dtype):
+        gate.wait(5)
+        return np.empty(shape, dtype)
+    pool = sharding.PinnedPool(slow_alloc, cap_bytes=2 * 1000 * 4)   # room for two 1000-float blocks
+    got = []
+
+    def worker():
+        started.wait(5)
+        got.append(pool.take(1000, 1))
+    ts = [threading.Thread(target=worker) for _ in range(4)]
+    for t in ts:
+        t.start()
+    started.wait(5)
+    import time
+    time.sleep(0.2)          # every worker has passed (or been refused at) the cap check; the two admitted ones sit in slow_alloc
+    gate.set()
+    for t in ts:
+        t.join()
+    assert pool.pinned_bytes() == 2 * 1000 * 4      # two leases; the other two requests got pageable arrays
+    assert sum(1 for a in got if pool.give(a)) == 2
+
+    def bad_alloc(shape, dtype):
+        raise MemoryError("hipHostMalloc failed")
+    pool2 = sharding.PinnedPool(bad_alloc)
+    a = pool2.take(10, 10)
+    assert a.shape == (10, 10) and pool2.pinned_bytes() == 0
