@@ -2102,13 +2102,14 @@ struct am_decoder {
     float PIP = 0.f;
     DevBuf endIdx, tri_idx, tri_self, tri_trans, outOff, outVal, lm, p0;
     DevBuf d_slot;       // frame-synchronous form: slot -> utterance
+    DevBuf d_slot_row;   // ... and slot -> first row of that utterance
     DevBuf cmp0, cmp1;   // compact 32-B graph records (nodes and posterior columns < 65536), see viterbi_compact_kernel
     bool has_compact = false;
     int form = AM_VITERBI_AUTO;   // am_decoder_set_form
     int perm = 0, inv0 = 0;   // compact records stored in arrival-list order (see ViterbiArgs::perm)
     DevBuf d_lp, d_off, pp, tt, pout, p, p2, inv0_state, bestI, bestT, seg_begin, seg_end, seg_tri, seg_count;
     DevBuf blk_tri0, blk_node0;   // fused frame-synchronous form (viterbi_fs_fused_kernel): blocks of whole arrival lists, <= 2,048 triphones each
-    int n_blk = 0;
+    int n_blk = 0, blk_nodes_max = 0;
 };
 
 template <class Tt>
@@ -2203,7 +2204,7 @@ extern "C" int am_decoder_create(am_engine* e, int numPhones, int numBiphones, i
             }
             bt.push_back(T); bn.push_back(B);
             if (fits && (rc = upload_raw(e, d->blk_tri0, bt.data(), bt.size())) == AM_OK && (rc = upload_raw(e, d->blk_node0, bn.data(), bn.size())) == AM_OK)
-                d->n_blk = (int)bt.size() - 1;
+            { d->n_blk = (int)bt.size() - 1; for (size_t bi = 0; bi + 1 < bn.size(); ++bi) d->blk_nodes_max = std::max(d->blk_nodes_max, bn[bi + 1] - bn[bi]); }
             if (rc != AM_OK) { am_decoder_destroy(d); return rc; }
         }
     }
@@ -2230,7 +2231,7 @@ extern "C" int am_decoder_destroy(am_decoder* d)
     if (!d) return AM_OK;
     (void)hipSetDevice(d->e->device);
     (void)hipStreamSynchronize(d->e->stream);
-    for (DevBuf* b : {&d->d_slot, &d->cmp0, &d->cmp1, &d->endIdx, &d->tri_idx, &d->tri_self, &d->tri_trans, &d->outOff, &d->outVal, &d->lm, &d->p0, &d->d_lp, &d->d_off,
+    for (DevBuf* b : {&d->d_slot, &d->d_slot_row, &d->cmp0, &d->cmp1, &d->endIdx, &d->tri_idx, &d->tri_self, &d->tri_trans, &d->outOff, &d->outVal, &d->lm, &d->p0, &d->d_lp, &d->d_off,
                       &d->pp, &d->tt, &d->pout, &d->p, &d->p2, &d->inv0_state, &d->blk_tri0, &d->blk_node0, &d->bestI, &d->bestT, &d->seg_begin, &d->seg_end, &d->seg_tri, &d->seg_count})
         b->release();
     am_engine* e = d->e;
@@ -2281,7 +2282,7 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
     a.lm = d->lm.as<float>(); a.p0 = d->p0.as<float>(); a.PIP = d->PIP;
     a.lp = lp_dev; a.ldl = ld; a.offsets = d->d_off.as<long long>();
     a.p2 = d->p2.as<float>(); a.inv0_state = d->inv0_state.as<int>();
-    a.blk_tri0 = d->blk_tri0.as<int>(); a.blk_node0 = d->blk_node0.as<int>(); a.n_blk = d->n_blk;
+    a.blk_tri0 = d->blk_tri0.as<int>(); a.blk_node0 = d->blk_node0.as<int>(); a.n_blk = d->n_blk; a.blk_nodes_max = d->blk_nodes_max;
     a.pp = d->pp.as<float>(); a.tt = d->tt.as<int>(); a.pout = d->pout.as<float>(); a.p = d->p.as<float>(); a.bestI = d->bestI.as<int>(); a.bestT = d->bestT.as<int>();
     a.seg_begin = d->seg_begin.as<int>(); a.seg_end = d->seg_end.as<int>(); a.seg_tri = d->seg_tri.as<int>(); a.seg_count = d->seg_count.as<int>();
     static const int64_t fs_env = env_int("AM_VITERBI_FS", 1);
@@ -2298,6 +2299,10 @@ static int decode_device(am_decoder* d, const float* lp_dev, int64_t ld, const i
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return offsets[x + 1] - offsets[x] > offsets[y + 1] - offsets[y]; });
         AM_TRY(upload_raw(e, d->d_slot, order.data(), order.size()));
         a.slot_utt = d->d_slot.as<int>();
+        std::vector<long long> slot_row(n_utts);
+        for (int sl = 0; sl < n_utts; ++sl) slot_row[sl] = offsets[order[sl]];
+        AM_TRY(upload_raw(e, d->d_slot_row, slot_row.data(), slot_row.size()));
+        a.slot_row0 = d->d_slot_row.as<long long>(); a.n_cus = e->n_cus;
         // (the launch sequence replayed as ONE hipGraph launch takes the same device time -- 78.7 ms both ways on the round-2 kernels: the host
         // enqueues the ~1,280 launches in 3 ms, the boundaries are not the cost)
         int rc = run_kernel(e, K_VITERBI, [&] { return launch_viterbi_fs_init(e->stream, a, n_utts); });

@@ -214,6 +214,7 @@ hipError_t init_split_kernels();
 hipError_t init_lstm_kernels();
 hipError_t init_rec_kernels();
 hipError_t init_stack_kernel();
+hipError_t init_viterbi_kernels();
 
 hipError_t init_kernels()
 {
@@ -222,6 +223,8 @@ hipError_t init_kernels()
     se = init_lstm_kernels();
     if (se != hipSuccess) return se;
     se = init_rec_kernels();
+    if (se != hipSuccess) return se;
+    se = init_viterbi_kernels();
     if (se != hipSuccess) return se;
     // per device: allow the GEMM's large dynamic LDS
     hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_f32_kernel<256, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_256);

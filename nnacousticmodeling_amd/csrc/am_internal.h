@@ -1,4 +1,5 @@
-// Internal interface between the C-ABI host layer (am_api.hip) and the gfx950 kernels (am_kernels.hip).
+// Internal interface between the C-ABI host layer (am_api.hip) and the gfx950 kernels (am_gemm.hip, am_gemm_split.hip, am_frontend.hip,
+// am_lstm_step.hip, am_lstm_persist.hip, am_cells.hip, am_viterbi.hip; device-side helpers they share: am_device.h).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -232,12 +233,15 @@ struct ViterbiArgs {
     int* seg_begin; int* seg_end; int* seg_tri;  // [N] segments of utterance u at [offsets[u], offsets[u] + seg_count[u]), last first
     int* seg_count;                    // [n_utts]
     const int* slot_utt;               // frame-synchronous form: utterance of each slot (slots sorted by length, longest first)
+    const long long* slot_row0;        // ... and the row of its first frame, offsets[slot_utt[slot]] (one scalar load instead of two dependent ones)
+    int n_cus;                         // CUs of the device (viterbi_fs_stream_kernel sizes its grid to the blocks the device holds at once)
     // frame-synchronous form: the node scores ping-pong between `p` (read by even frames, written by odd ones) and `p2` (the reverse), so that a
     // launch that updates triphones AND takes the node maxima never overwrites a score another block of the same frame still has to read
     float* p2;
     // fused form (viterbi_fs_fused_kernel; perm == 1): block b covers the whole arrival lists of nodes [blk_node0[b], blk_node0[b+1]) =
     // triphones [blk_tri0[b], blk_tri0[b+1]) (at most 2,048); inv0_state: [n_utts][2][8] ints, the state of triphone inv0 BEFORE frame k at parity k & 1
     const int* blk_tri0; const int* blk_node0; int n_blk;
+    int blk_nodes_max;                 // most nodes any block covers (viterbi_fs_stream_kernel keeps their list bounds in LDS)
     int* inv0_state;
 };
 hipError_t launch_viterbi(hipStream_t s, const ViterbiArgs& a, int n_utts);

@@ -455,6 +455,184 @@ __global__ __launch_bounds__(NTHR) void viterbi_fs_fused_kernel(const ViterbiArg
     }
 }
 
+// The fused launch as a STREAM (round 4).  viterbi_fs_fused_kernel's block lives for one (slot, triphone block) item: scalar preamble, every load
+// in flight, wait, update, stores, node maxima, exit -- with two blocks per CU the memory pipe drains in every block's compute and node phases
+// and in the gaps between blocks, and each item re-fetches its 32 B of graph constants per triphone from L2 (64 KB of the 119 KB an item loads):
+// 4.3 TB/s at the fabric where a copy reaches 6.3.  Here a block keeps ONE triphone block for the whole launch and walks the slots g, g + G,
+// g + 2G, ...: the constants, the list bounds and the language-model terms of its nodes are loaded once per launch and stay in registers; slot
+// i + 1's state (18 B per triphone, into a second register set) and its two gather arrays (log-posterior row + node scores, by LDS-DMA into the
+// other half of a double buffer: no registers) are requested before slot i is updated, so a CU's loads never stop while it computes.
+// G = resident blocks / triphone blocks (2 x 256 / 44 = 11 at the real size); a launch with fewer active utterances than that runs one slot per
+// block.  Same arithmetic, comparisons, tie-breaking and store order per address as the fused kernel: bit-identical segmentations.
+// Threads past the end of a short block repeat its last triphone (same loads, same results, same stores): every wave issues the same number of
+// vector-memory operations per slot, nothing is predicated in the update.
+struct VitSlotState { i32x4 qa[2], qb[2]; int ta[2], tb[2]; };
+
+template <int NTHR>
+__global__ __launch_bounds__(NTHR, (2 * NTHR) / 256) void viterbi_fs_stream_kernel(const ViterbiArgs a, int k, int n_active, int G, int xcd_map)
+{
+    constexpr int CAP = 2048, IT = CAP / (2 * NTHR), HALF = NTHR;
+    static_assert(IT == 2, "VitSlotState holds two trips");
+    extern __shared__ float vsm[];
+    const int T = a.T, B = a.B, L = (int)a.ldl;
+    const int SB = (L + B + NTHR - 1) / NTHR * NTHR;           // floats per staging buffer: [L] log-posteriors of frame k, [B] node scores, padding
+    float* s_po = vsm + 2 * SB;
+    int* s_t2 = (int*)(s_po + CAP);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (slot group, triphone block) of this workgroup.  The blocks of a slot group stage the same log-posterior rows and node scores; under
+    // round-robin placement (workgroup id % 8 = XCD: speed only) the first 8 groups get an XCD each, so that those 17 KB per slot are fetched
+    // into one L2 instead of eight; the remaining groups are dealt over all XCDs.
+    int grp, blk;
+    {
+        const int id = blockIdx.x, nb = a.n_blk;
+        if (xcd_map && G >= 8 && id < 8 * nb) { grp = id & 7; blk = id >> 3; }   // the first 8 groups: one XCD each
+        else { grp = id / nb; blk = id - grp * nb; }                            // (ids >= 8 * nb: groups 8 .. G - 1, over all XCDs)
+    }
+    const int tri0 = a.blk_tri0[blk], tri1 = a.blk_tri0[blk + 1];
+    const int node0 = a.blk_node0[blk], node1 = a.blk_node0[blk + 1];
+    const i32x4* c0 = (const i32x4*)a.tri_idx;
+    const f32x4* c1 = (const f32x4*)a.tri_self;
+    // per launch: this thread's triphones, their graph constants, its nodes' list bounds
+    int na[IT], nb[IT];
+    i32x4 ga[IT], gb[IT]; f32x4 ha[IT], hb[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int n0 = tri0 + tid + it * 2 * HALF;
+        na[it] = n0 < tri1 ? n0 : tri1 - 1; nb[it] = n0 + HALF < tri1 ? n0 + HALF : tri1 - 1;
+        ga[it] = c0[na[it]]; gb[it] = c0[nb[it]]; ha[it] = c1[na[it]]; hb[it] = c1[nb[it]];
+    }
+    // the list bounds and language-model terms of this block's nodes: per launch, in LDS (registers are what bounds this kernel's occupancy)
+    int* s_ns = (int*)(s_t2 + CAP);                           // [nodes + 1] list bounds, then [nodes] lm terms
+    const int n_nodes = node1 - node0;
+    for (int i = tid; i <= n_nodes; i += NTHR) s_ns[i] = a.outOff[node0 + i];
+    for (int i = tid; i < n_nodes; i += NTHR) ((float*)s_ns)[n_nodes + 1 + i] = a.lm[node0 + i];
+    // state accesses: buffer instructions (resource in SGPRs, a slot's base as the scalar offset, ONE 32-bit per-thread offset per triphone:
+    // no 64-bit address registers per access); nt = streamed once per launch
+    const __amdgpu_buffer_rsrc_t rs_pp = __builtin_amdgcn_make_buffer_rsrc((void*)a.pp, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_t2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.tt, 0, 0x7fffffff, 0x00020000);
+    constexpr int NT = 2;   // aux: nt
+    // The first rows of the slots' utterances travel two slots ahead of their use, in SGPRs: the compiler cannot prove the table constant (the
+    // kernel stores through other pointers), so a look-up at the point of use is a VECTOR load whose wait -- vmcnt counts in order -- would also
+    // wait for the state loads just requested for the next slot.
+    auto uniform64 = [](long long v) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+        return (long long)(((unsigned long long)hi << 32) | lo);
+    };
+    long long row_cur = 0, row_nxt = 0;
+    auto request = [&](int slot, long long row0, VitSlotState& S, int buf) {   // everything slot `slot` needs, in flight
+        const long long row = row0 + k;
+        const float* lp1 = a.lp + (size_t)row * a.ldl;
+        const float* p = ((k & 1) ? a.p2 : a.p) + (size_t)slot * B;
+        const int so_pp = slot * T * 16, so_t2 = slot * T * 2;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            S.qa[it] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_pp, na[it] * 16, so_pp, NT));
+            S.qb[it] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_pp, nb[it] * 16, so_pp, NT));
+            S.ta[it] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs_t2, na[it] * 2, so_t2, NT);
+            S.tb[it] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs_t2, nb[it] * 2, so_t2, NT);
+        }
+        float* stage = vsm + buf * SB;
+        for (int i0 = wave * 64; i0 < L + B; i0 += NTHR) {      // one 256-B LDS-DMA piece per wave and trip; lanes past the end repeat the last word
+            int i = i0 + lane;
+            i = i < L + B ? i : L + B - 1;
+            const float* src = i < L ? lp1 + i : p + (i - L);
+            __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(src), AM_LDS_PTR(stage + i0), 4, 0, 0);
+        }
+    };
+    auto advance = [&](int slot, const VitSlotState& S, VitSlotState& N, int buf) {
+        long long row_n2 = 0;
+        if (slot + 2 * G < n_active) row_n2 = a.slot_row0[slot + 2 * G];   // (lands under the wait below)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this slot's state and this wave's staging pieces have landed ...
+        row_n2 = uniform64(row_n2);
+        __syncthreads();                                       // ... everyone's have; everyone is done with the previous slot's node phase
+        if (slot + G < n_active) request(slot + G, row_nxt, N, buf ^ 1);
+        const float* s_lp = vsm + buf * SB;
+        const float* s_p = s_lp + L;
+        const long long row = row_cur + k;
+        row_cur = row_nxt; row_nxt = row_n2;
+        float* pnext = ((k & 1) ? a.p : a.p2) + (size_t)slot * B;
+        const int so_pp = slot * T * 16, so_t2 = slot * T * 2;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            i32x4 nqa, nqb; int nta, ntb; float poa, pob;
+            // (the packed gather indices are made opaque per slot: loop-invariant code motion would otherwise keep the 32 LDS addresses derived
+            //  from them -- 4 triphones x 4 gathers x 2 buffers -- in registers across the slot loop, which is what this kernel has none to spare of)
+            asm volatile("" : "+v"(ga[it][0]), "+v"(ga[it][1]), "+v"(gb[it][0]), "+v"(gb[it][1]));
+            {
+                const i32x4 g = ga[it];
+                viterbi_tri_apply(g, ha[it], S.qa[it], S.ta[it], s_p[g[0] & 0xffff], s_lp[(unsigned)g[0] >> 16], s_lp[g[1] & 0xffff], s_lp[(unsigned)g[1] >> 16], a.PIP, k, nqa, nta, poa);
+            }
+            {
+                const i32x4 g = gb[it];
+                viterbi_tri_apply(g, hb[it], S.qb[it], S.tb[it], s_p[g[0] & 0xffff], s_lp[(unsigned)g[0] >> 16], s_lp[g[1] & 0xffff], s_lp[(unsigned)g[1] >> 16], a.PIP, k, nqb, ntb, pob);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, nqa), rs_pp, na[it] * 16, so_pp, NT);
+            __builtin_amdgcn_raw_buffer_store_b16((short)nta, rs_t2, na[it] * 2, so_t2, NT);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, nqb), rs_pp, nb[it] * 16, so_pp, NT);
+            __builtin_amdgcn_raw_buffer_store_b16((short)ntb, rs_t2, nb[it] * 2, so_t2, NT);
+            s_po[na[it] - tri0] = poa; s_t2[na[it] - tri0] = nta; s_po[nb[it] - tri0] = pob; s_t2[nb[it] - tri0] = ntb;
+            const int mine = (na[it] == a.inv0 ? 1 : 0) | (nb[it] == a.inv0 ? 2 : 0);
+            if (mine) {   // the owner of the reference's triphone 0 leaves its state for the next frame's unreachable nodes
+                int* st = a.inv0_state + (size_t)slot * 16 + ((k + 1) & 1) * 8;
+                const i32x4 q = (mine & 1) ? nqa : nqb;
+                st[0] = q[0]; st[1] = q[1]; st[2] = q[2]; st[3] = q[3]; st[4] = (mine & 1) ? nta : ntb;
+            }
+        }
+        // the exit scores and entry times are in LDS for everyone -- a barrier that does NOT drain vector memory: __syncthreads() would wait
+        // for the next slot's loads requested above (and for this slot's stores), which is the overlap this kernel exists for
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // node maxima: 8 lanes per node, the first strict maximum in list order (viterbi_fs_fused_kernel's node phase)
+        const int l8 = tid & 7;
+        for (int i0 = node0; i0 < node1; i0 += NTHR / 8) {
+            const int i = i0 + (tid >> 3);
+            const bool valid = i < node1;
+            const int s0 = valid ? s_ns[i - node0] : 0, s1 = valid ? s_ns[i - node0 + 1] : 0;
+            const float lmi = valid ? ((const float*)s_ns)[n_nodes + 1 + i - node0] : 0.0f;
+            float mx = -1e20f; int ms = 0x7fffffff, mxi = 0;
+            for (int s2 = s0 + l8; s2 < s1; s2 += 8) {
+                const float pOut = s_po[s2 - tri0];
+                if (mx < pOut) { mx = pOut; ms = s2; mxi = s2; }
+            }
+#pragma unroll
+            for (int off = 4; off > 0; off >>= 1) {
+                const float omx = __shfl_xor(mx, off);
+                const int oms = __shfl_xor(ms, off), omi = __shfl_xor(mxi, off);
+                if (omx > mx || (omx == mx && oms < ms)) { mx = omx; ms = oms; mxi = omi; }
+            }
+            if (valid && l8 == 0) {
+                int bt;
+                if (ms == 0x7fffffff) {   // nothing exceeded -1e20: triphone inv0 and its entry time after THIS frame's update
+                    mxi = a.inv0;
+                    const int* st = a.inv0_state + (size_t)slot * 16 + (k & 1) * 8;
+                    const f32x4 h0 = c1[a.inv0];
+                    const float q1 = __int_as_float(st[1]), q2 = __int_as_float(st[2]);
+                    const int t1s = (unsigned)st[3] >> 16, t2s = st[4];
+                    bt = ((q1 + h0[2] > q2 + h0[0]) ? t1s : t2s) - 1;
+                } else {
+                    bt = s_t2[mxi - tri0] - 1;
+                }
+                pnext[i] = mx + lmi;
+                a.bestI[(size_t)row * B + i] = mxi;
+                a.bestT[(size_t)row * B + i] = bt;
+            }
+        }
+    };
+    VitSlotState SA, SBs;
+    int slot = grp;
+    if (slot >= n_active) return;
+    row_cur = uniform64(a.slot_row0[slot]);
+    row_nxt = slot + G < n_active ? uniform64(a.slot_row0[slot + G]) : 0;
+    request(slot, row_cur, SA, 0);
+    for (;;) {
+        advance(slot, SA, SBs, 0);
+        slot += G;
+        if (slot >= n_active) break;
+        advance(slot, SBs, SA, 1);
+        slot += G;
+        if (slot >= n_active) break;
+    }
+}
+
 __global__ __launch_bounds__(64) void viterbi_fs_trace_kernel(const ViterbiArgs a, int n_utts)
 {
     const int slot = blockIdx.x * 64 + threadIdx.x;
@@ -488,6 +666,12 @@ __global__ __launch_bounds__(64) void viterbi_fs_trace_kernel(const ViterbiArgs 
     a.seg_count[u] = ok ? count : 0;
 }
 
+constexpr size_t VITERBI_STREAM_LDS_MAX = 80 * 1024;   // two blocks per CU
+hipError_t init_viterbi_kernels()
+{
+    return hipFuncSetAttribute((const void*)viterbi_fs_stream_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VITERBI_STREAM_LDS_MAX);
+}
+
 hipError_t launch_viterbi_fs_init(hipStream_t s, const ViterbiArgs& a, int n_utts)
 {
     if (n_utts <= 0) return hipSuccess;
@@ -501,6 +685,20 @@ hipError_t launch_viterbi_fs_step(hipStream_t s, const ViterbiArgs& a, int k, in
     const char* sv = getenv("AM_VITERBI_LDS");       // (measurement: 0 = every launch on the form that gathers from global memory; 1 = staged, node maxima in their own launch)
     const size_t lds = ((size_t)a.ldl + (size_t)a.B) * sizeof(float);
     const char* fm = getenv("AM_VITERBI_FUSED_MIN");
+    const char* stv = getenv("AM_VITERBI_STREAM");   // 0: viterbi_fs_fused_kernel (A/B timing, cross-form tests); > 1: that many slot groups; read per launch like the others
+    const int stream_mode = stv ? atoi(stv) : 1;
+    // two staging buffers, exit scores + entry times of a block's <= 2,048 triphones, list bounds + lm terms of its nodes
+    const size_t stream_lds = (2 * ((size_t)(a.ldl + a.B + 511) / 512 * 512) + 2 * 2048 + 2 * (size_t)a.blk_nodes_max + 2) * sizeof(float);
+    if (stream_mode && (!sv || atoi(sv) > 2) && a.n_blk > 0 && a.perm && a.slot_row0 && a.blk_nodes_max > 0 && stream_lds <= VITERBI_STREAM_LDS_MAX &&
+        (size_t)n_active * a.T * 16 < 0x7fffffffu) {   // (a slot's state is addressed by a 32-bit buffer offset)
+        // slots per block: as many blocks as the device holds at once (two per CU), each walking n_active / G slots
+        int G = std::max(1, 2 * std::max(a.n_cus, 1) / a.n_blk);
+        if (stream_mode > 1) G = stream_mode;   // (measurement: a given number of slot groups)
+        G = std::min(G, n_active);
+        const char* xm = getenv("AM_VITERBI_XCD_MAP");   // (measurement: 0 = groups in workgroup-id order)
+        hipLaunchKernelGGL(viterbi_fs_stream_kernel<512>, dim3(a.n_blk * G), dim3(512), stream_lds, s, a, k, n_active, G, xm ? atoi(xm) : 1);
+        return hipGetLastError();
+    }
     if ((!sv || atoi(sv) > 1) && a.n_blk > 0 && a.perm && lds + 2 * 2048 * sizeof(float) <= 48 * 1024 && n_active >= (fm ? atoi(fm) : 1)) {   // (to the last utterance: 48.1 ms per real-size pass against 48.6 with the gathering form below 12 active ones)
         // 512 threads x 4 triphones: 50.8 ms per real-size pass; 256 x 8: 52.7; 1,024 x 2: 59.2 (AM_VITERBI_THREADS=256 for A/B timing)
         const char* tv = getenv("AM_VITERBI_THREADS");

@@ -101,8 +101,16 @@ def test_frame_sync_lds_form_matches_the_other_forms(engine, P, S, monkeypatch):
     lp = np.concatenate(lps)
     dec = PhoneRecog(engine, dict(graph, numPhones=P, numBiphones=len(graph["lm"]), numTriphones=len(graph["biphoneIdxIn"])), -6.0, 0.8)
     dec.set_form("frame_sync")
-    monkeypatch.setenv("AM_VITERBI_LDS", "2")   # the default: triphone update and node maxima in one launch (blocks of whole arrival lists)
+    monkeypatch.delenv("AM_VITERBI_LDS", raising=False)
+    stream = dec.recognise(lp, offsets)         # the default (round 4): the fused launch as a stream, a block walks several utterance slots
+    monkeypatch.setenv("AM_VITERBI_STREAM", "3")   # three slot groups: every block walks up to 14 of the 40 slots (odd and even trip counts)
+    stream3 = dec.recognise(lp, offsets)
+    monkeypatch.setenv("AM_VITERBI_STREAM", "40")  # one slot per block
+    stream40 = dec.recognise(lp, offsets)
+    monkeypatch.delenv("AM_VITERBI_STREAM")
+    monkeypatch.setenv("AM_VITERBI_LDS", "2")   # round 3's form: triphone update and node maxima in one launch, a block per (slot, triphone block)
     fused = dec.recognise(lp, offsets)
+    assert stream == stream3 == stream40 == fused
     monkeypatch.setenv("AM_VITERBI_LDS", "1")   # staged gathers, node maxima in their own launch
     staged = dec.recognise(lp, offsets)
     monkeypatch.setenv("AM_VITERBI_LDS", "0")

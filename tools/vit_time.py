@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Device time of the real-size decoder pass (192 utterances / 57,919 frames) by 64-frame segments (AM_VITERBI_TIMING=2), per kernel form
-(AM_VITERBI_LDS = 2 fused, 1 staged + node kernel, 0 gathers from global memory).  Diagnostic only."""
+(AM_VITERBI_LDS = 3 stream (default), 2 fused, 1 staged + node kernel, 0 gathers from global memory).  Diagnostic only."""
 import os
 import sys
 import time
@@ -21,7 +21,7 @@ z = rng.standard_normal((n57, 1909), dtype=np.float32)
 eng = Engine(0)
 dec = PhoneRecog(eng, dict(graph, numPhones=48, numBiphones=B_, numTriphones=T_), -20.0, 1.0)
 ref = None
-for form in (sys.argv[1:] or ["2", "1"]):
+for form in (sys.argv[1:] or ["3", "2"]):
     os.environ["AM_VITERBI_LDS"] = form
     for i in range(2):
         t0 = time.perf_counter()
