@@ -1580,7 +1580,23 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
             auto& pl = p->persist[mi];
             const int U_pad = m->L[0].U_pad;
             const int max_wgs = lstm_persist_resident_wgs(U_pad, e->n_cus);
-            if (lstm_persist_capacity(U_pad, 1, max_wgs) <= 0) continue;
+            if (lstm_persist_capacity(U_pad, 1, max_wgs) <= 0) {
+                // no register-resident form for this width: the streamed persistent form (lstm_stream_kernel: 768 / 1024 units), every utterance in
+                // one launch per segment of as many layers as the device holds workgroups for (4 x 1024: one launch of 256 workgroups)
+                static const bool stream_ok = env_int("AM_LSTM_STREAM", 1) != 0;
+                const int swgs = stream_ok ? lstm_stream_resident_wgs(U_pad, e->n_cus) : 0;
+                const int lmax = lstm_stream_layers(U_pad, swgs);
+                if (lmax < 1) continue;
+                for (int l0 = 0; l0 < m->n_layers; l0 += lmax) {
+                    LstmPersistArgs pa{};
+                    pa.n_layers = std::min(lmax, m->n_layers - l0); pa.U_pad = U_pad; pa.T = (int)T; pa.slot_base = 0; pa.slot_cap = n_utts;
+                    pa.max_wgs = swgs; pa.ext_upward = l0 > 0 ? 1 : 0;
+                    pl.chunks.push_back(pa);
+                    pl.layer0.push_back(l0);
+                }
+                pl.form = 2; any_persist = true;
+                continue;
+            }
             // Layer segments.  A launch holds every layer of its segment at once, so the slots it can take shrink with the layer count (3 x 512:
             // 192 utterances, 4 x 512: 128, 5 x 512: 64), and a file that does not fit runs as several launches over chunks of its utterances, each
             // walking the whole time axis of its longest utterance.  A deep stack is cheaper cut the other way: the first launch runs as many layers
@@ -1659,7 +1675,7 @@ extern "C" int am_pipeline_recurrent_form(am_pipeline* p, int* n_persistent, int
     if (!p || !n_persistent || !n_members || p->mode != 2) return fail(AM_EINVAL, "am_pipeline_recurrent_form: nothing uploaded (am_lstm_upload)");
     *n_members = (int)p->members.size();
     *n_persistent = 0;
-    for (auto& pl : p->persist) *n_persistent += pl.form == 1;
+    for (auto& pl : p->persist) *n_persistent += pl.form != 0;
     return AM_OK;
 }
 
@@ -1697,13 +1713,13 @@ extern "C" int am_lstm_run(am_pipeline* p)
     // a give-up on this device is sticky for EVERY pipeline, also those that planned the persistent form before it happened (another
     // engine or shard on the same card): they drop their plan here instead of each paying its own 2-s stall
     if (gate_of(e).off.load())
-        for (auto& pl : p->persist) if (pl.form == 1) pl.release();
+        for (auto& pl : p->persist) if (pl.form != 0) pl.release();
     auto eager = [&] { const int rc = lstm_enqueue(p); if (rc != AM_OK) p->results_valid = false; return rc; };
     // with the persistent form a pass is a handful of launches on two streams: nothing to gain from a graph, and a replayed
     // graph serialises the second stream's branch (measured: 10.2 ms replayed against 8.8 ms eager)
     // (and a pass with a persistent launch in it waits for another engine's event, which a stream capture does not admit)
     bool any_persistent = false;
-    for (auto& pl : p->persist) any_persistent = any_persistent || pl.form == 1;
+    for (auto& pl : p->persist) any_persistent = any_persistent || pl.form != 0;
     if (e->profile || any_persistent || !lstm_use_graph()) return eager();   // per-kernel events need eager launches
     if (p->graph_exec) { HIP_TRY(hipGraphLaunch(p->graph_exec, e->stream)); return AM_OK; }
     if (p->lstm_runs++ == 0) return eager();          // one-shot use: eager (no capture / instantiate cost)
@@ -1839,7 +1855,33 @@ static int lstm_enqueue(am_pipeline* p)
         }
         float* Hall = p->d_H.as<float>();
         float* Call = p->d_c.as<float>();
-        if (p->persist[mi].form == 1) {
+        if (p->persist[mi].form == 2) {
+            // the whole stack and time axis in one persistent launch per layer segment, weights streamed (lstm_stream_kernel)
+            float* Cplanes = p->d_cplane.as<float>();
+            const size_t n_chunks = p->persist[mi].chunks.size();
+            for (size_t ci = 0; ci < n_chunks; ++ci) {
+                LstmPersistArgs pa = p->persist[mi].chunks[ci];
+                const int lbase = p->persist[mi].layer0[ci];
+                for (int l = lbase; l < lbase + pa.n_layers; ++l) {
+                    Layer& Ly = m->L[l];
+                    LstmPersistLayer& s = pa.L[l - lbase];
+                    s.G = l == 0 ? p->d_G.as<float>() : nullptr;
+                    s.bias = Ly.b.as<float>(); s.Wup = l == 0 ? nullptr : Ly.W.as<float>(); s.Wlat = Ly.Wlat.as<float>();
+                    s.Hin = l == 0 ? nullptr : Hall + (l - 1) * h_stride;
+                    s.H = Hall + l * h_stride; s.Cst = Cplanes + l * h_stride;
+                }
+                pa.n_active = p->d_nact.as<int>(); pa.step_off = p->d_stepoff.as<int>();
+                pa.counters = p->d_sync.as<unsigned>(); pa.abort_flag = p->d_sync.as<int>() + 63;
+                HIP_TRY(hipMemsetAsync(p->d_sync.p, 0, sizeof(unsigned) * 63, e->stream));   // the abort flag (last word) is cleared once per pass
+                PersistGate& G = gate_of(e);   // one persistent launch at a time per device: every workgroup must be resident
+                std::lock_guard<std::mutex> lk(G.mu);
+                if (G.last && G.owner != e) HIP_TRY(hipStreamWaitEvent(e->stream, G.last, 0));
+                AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_lstm_stream(e->stream, pa); }));
+                HIP_TRY(hipEventRecord(e->persist_done, e->stream));
+                G.last = e->persist_done; G.owner = e;
+            }
+            p->used_persist = true;
+        } else if (p->persist[mi].form == 1) {
             float* Cplanes = p->d_cplane.as<float>();
             // the whole stack and time axis in one persistent launch per chunk of utterance slots (lstm_persist_kernel)
             static const bool want_stamps = env_int("AM_LSTM_STAMPS", 0) != 0;

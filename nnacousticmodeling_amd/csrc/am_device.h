@@ -64,6 +64,18 @@ __device__ __forceinline__ float am_activate_rec(float v, int act) {
     return am_tanh_rec(v);
 }
 
+// 16-B accesses of rows another workgroup of the SAME launch stored / will load (hand-offs of the persistent kernels): write-through stores,
+// L1-bypassing loads (MI355X_MICROARCH.md, inter-workgroup visibility)
+__device__ __forceinline__ f32x4 ld_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16 /* sc1 */));
+}
+
+__device__ __forceinline__ void st_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, 0, 16 /* sc1 */);
+}
+
 // geometry shared by the GEMM kernels (am_gemm.hip, am_gemm_split.hip): 512-thread blocks, 8 waves as 4 (M) x 2 (N)
 constexpr int GEMM_WM = 4, GEMM_WN = 2, GEMM_THREADS = 64 * GEMM_WM * GEMM_WN;
 

@@ -187,6 +187,13 @@ hipError_t launch_lstm_persist(hipStream_t s, const LstmPersistArgs& a);
 
 int lstm_persist_mode();   // AM_LSTM_PERSIST: 0 per-step kernels, 1 (default) the persistent form
 
+// The persistent form for stacks whose weights do not fit the register file (lstm_stream_kernel: 768 / 1024 units): the same arguments, workgroup =
+// (layer, 16-unit tile) taking all active rows, weights streamed per step; counters[l] = arrivals of layer l (U_pad / 16 per step); `cum`, the group
+// fields and `stamps` are unused.
+int lstm_stream_resident_wgs(int U_pad, int n_cus);       // co-resident workgroups of the kernel (0: this shape has no streamed form)
+int lstm_stream_layers(int U_pad, int max_wgs);           // layers one launch can take
+hipError_t launch_lstm_stream(hipStream_t s, const LstmPersistArgs& a);
+
 // Recurrent cells other than L.LSTM (GRU / MGRU / peephole LSTM): one phase of one wavefront tick, see rec_step_kernel.
 enum RecEpilogue {
     REC_MGRU = 0,    // 2 gates (z, h~):   h = z*act(h~) + (1-z)*h_prev                               (MGRU.py:67-85, no reset gate)

@@ -32,15 +32,6 @@ namespace am {
 // Every wait is bounded (2 s of the 100 MHz counter): a timeout raises `abort_flag`, every workgroup leaves, the host
 // reports an error instead of hanging the GPU.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ f32x4 ld_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
-{
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16 /* sc1 */));
-}
-
-__device__ __forceinline__ void st_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v)
-{
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, 0, 16 /* sc1 */);
-}
 
 // Wave 0, lane j < n polls counter first + j until it reaches cum[(first + j) * T + tcol]; then the workgroup's barrier.
 // Returns false (all threads) when the pass has been aborted.

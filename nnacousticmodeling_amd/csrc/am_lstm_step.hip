@@ -452,12 +452,15 @@ static int lstm_wreg_mode()
 }
 
 hipError_t init_lstm_persist_kernels();   // am_lstm_persist.hip
+hipError_t init_lstm_stream_kernels();    // am_lstm_stream.hip
 
 hipError_t init_lstm_kernels()
 {
     hipError_t we = hipFuncSetAttribute((const void*)lstm_wreg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_WREG_LDS);
     if (we != hipSuccess) return we;
     we = init_lstm_persist_kernels();
+    if (we != hipSuccess) return we;
+    we = init_lstm_stream_kernels();
     if (we != hipSuccess) return we;
 
     we = hipFuncSetAttribute((const void*)lstm_wreg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSTM_WREG_PAIR_LDS);

@@ -114,12 +114,13 @@ def test_recurrent_forms_agree_bit_for_bit(engine, real_ft_path, monkeypatch):
         p.close()
 
 
-@pytest.mark.parametrize("layers,units", [(2, 512), (4, 512), (5, 512), (6, 256)])
+@pytest.mark.parametrize("layers,units", [(2, 512), (4, 512), (5, 512), (6, 256), (4, 1024), (5, 1024), (2, 768)])
 def test_reference_recipe_shapes_agree_across_recurrent_forms(engine, real_ft_path, monkeypatch, layers, units):
     """The LSTM shapes the reference's recipes train (scripts/papers/tsd2018/run.sh:33-41: 2..6 layers x 256 / 512 units,
-    --timedelay 5): deeper stacks change the persistent kernel's plan -- fewer row groups per layer, more row tiles per group,
-    fewer utterance slots per launch (several chunks), other tile counts in the 256-k step form -- and every plan must give the
-    per-step kernels' bits; plus the oracle on a sample."""
+    --timedelay 5; scripts/papers/specom2018/run.sh:9: 4 x 1024): deeper stacks change the persistent kernel's plan -- fewer row groups
+    per layer, more row tiles per group, fewer utterance slots per launch (several chunks), other tile counts in the 256-k step form --
+    and the 768- / 1024-unit stacks take the streamed persistent form (lstm_stream_kernel: 150 utterances = two passes of 5 row tiles
+    per step at the start, 5 x 1024 = two layer segments); every plan must give the per-step kernels' bits; plus the oracle on a sample."""
     ft = orc.centre_frame_transform(orc.load_kaldi_feature_transform(real_ft_path))
     rng = np.random.default_rng(100 * layers + units)
     params = orc.make_lstm_params(rng, 40, units, layers, 1909)
