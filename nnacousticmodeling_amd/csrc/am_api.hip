@@ -1872,6 +1872,14 @@ static int lstm_enqueue(am_pipeline* p)
                 }
                 pa.n_active = p->d_nact.as<int>(); pa.step_off = p->d_stepoff.as<int>();
                 pa.counters = p->d_sync.as<unsigned>(); pa.abort_flag = p->d_sync.as<int>() + 63;
+                static const bool want_stamps2 = env_int("AM_LSTM_STAMPS", 0) != 0;
+                if (want_stamps2 && ci == 0) {   // diagnostic timeline: one row of stamps per layer (am_lstm_stamps)
+                    const size_t bytes = sizeof(unsigned long long) * 8 * (size_t)pa.n_layers * pa.T;
+                    AM_TRY(p->d_stamps.ensure(bytes));
+                    HIP_TRY(hipMemsetAsync(p->d_stamps.p, 0, bytes, e->stream));
+                    pa.stamps = p->d_stamps.as<unsigned long long>();
+                    p->stamps_groups = pa.n_layers; p->stamps_T = pa.T;
+                }
                 HIP_TRY(hipMemsetAsync(p->d_sync.p, 0, sizeof(unsigned) * 63, e->stream));   // the abort flag (last word) is cleared once per pass
                 PersistGate& G = gate_of(e);   // one persistent launch at a time per device: every workgroup must be resident
                 std::lock_guard<std::mutex> lk(G.mu);

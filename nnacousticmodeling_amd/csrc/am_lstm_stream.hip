@@ -36,11 +36,20 @@ __device__ __forceinline__ void stream_wait_vmcnt(int k)   // (k is a constant a
     AM_VMCNT_CASE(0) AM_VMCNT_CASE(1) AM_VMCNT_CASE(2) AM_VMCNT_CASE(3) AM_VMCNT_CASE(4) AM_VMCNT_CASE(5) AM_VMCNT_CASE(6) AM_VMCNT_CASE(7)
     AM_VMCNT_CASE(8) AM_VMCNT_CASE(9) AM_VMCNT_CASE(10) AM_VMCNT_CASE(11) AM_VMCNT_CASE(12) AM_VMCNT_CASE(13) AM_VMCNT_CASE(14) AM_VMCNT_CASE(15)
     AM_VMCNT_CASE(16) AM_VMCNT_CASE(17) AM_VMCNT_CASE(18) AM_VMCNT_CASE(19) AM_VMCNT_CASE(20) AM_VMCNT_CASE(21) AM_VMCNT_CASE(22) AM_VMCNT_CASE(23)
-    AM_VMCNT_CASE(24) AM_VMCNT_CASE(25) AM_VMCNT_CASE(26) AM_VMCNT_CASE(27) AM_VMCNT_CASE(28) AM_VMCNT_CASE(29) AM_VMCNT_CASE(30)
+    AM_VMCNT_CASE(24) AM_VMCNT_CASE(25) AM_VMCNT_CASE(26) AM_VMCNT_CASE(27) AM_VMCNT_CASE(28) AM_VMCNT_CASE(29) AM_VMCNT_CASE(30) AM_VMCNT_CASE(31)
+    AM_VMCNT_CASE(32) AM_VMCNT_CASE(33) AM_VMCNT_CASE(34) AM_VMCNT_CASE(35) AM_VMCNT_CASE(36) AM_VMCNT_CASE(37) AM_VMCNT_CASE(38) AM_VMCNT_CASE(39)
+    AM_VMCNT_CASE(40) AM_VMCNT_CASE(41) AM_VMCNT_CASE(42)
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
 #undef AM_VMCNT_CASE
+
+// diagnostic timeline (AM_LSTM_STAMPS=1): the ut == 0 workgroup of every layer stamps the 100 MHz counter into a buffer nothing else reads
+// (slots: 0 step start, 1 upward wait done, 2 first pass's products done, 4 every pass done, 6 published)
+__device__ __forceinline__ void stream_stamp(const LstmPersistArgs& a, int li, int ut, int t, int k)
+{
+    if (a.stamps && ut == 0 && threadIdx.x == 0) a.stamps[((size_t)li * a.T + t) * 8 + k] = __builtin_amdgcn_s_memrealtime();
+}
 
 // One lane polls `*c >= target`; then the workgroup's barrier.  false (all threads) when the pass has been aborted.
 __device__ __forceinline__ bool stream_wait(const LstmPersistArgs& a, const unsigned* c, unsigned target, int* s_flag)
@@ -69,15 +78,19 @@ __device__ __forceinline__ bool stream_wait(const LstmPersistArgs& a, const unsi
 // wave); stages are requested LEAD = NBUF - 1 ahead, always tile first, so the counted wait for stage b is (stages requested behind it) x (NT + 4).
 template <int NBU, int NBL, int NT>
 __device__ __forceinline__ bool stream_pass(const LstmPersistArgs& a, const LstmPersistLayer& Ly, int li, int ut, int t, int rows_valid, unsigned r_t, unsigned r_p,
-                                            unsigned lat_target, float* ring, int* s_flag)
+                                            unsigned lat_target, float* ring, int* s_flag, bool first_pass)
 {
     constexpr int NBT = NBU + NBL;
     constexpr int ROWS = NT * 16;
+    // tile ring: 3 x 96 rows (5-6 tiles) or 4 x 64 rows.  (Measured for 1-2 tiles: 8 x 32 rows, seven stages ahead instead of three, changes
+    // nothing -- 23.5 against 22.7 us per thin step: such a step moves 512 KB of weights per CU, 134 MB chip-wide, in ~21 us = 6.4 TB/s: it is
+    // bound by the rate at which the chip streams from the Infinity Cache / HBM, not by latency.)
     constexpr int BUF_ROWS = NT <= 4 ? 64 : 96;
     constexpr int NBUF = NT <= 4 ? 4 : 3;
     constexpr int LEAD = NBUF - 1;
     constexpr int BUF_FLOATS = BUF_ROWS * STREAM_TILE_LD;
     constexpr int PER_STAGE = NT + LSTM_KS;            // vector-memory instructions per wave and stage
+    static_assert(PER_STAGE * LEAD <= 42, "the counted waits cover at most 42 operations in flight (vmcnt is a 6-bit counter)");
     // (an opaque copy of the thread index per pass: the weight and tile addresses are invariant over the time loop, and hoisted out of it they would
     //  hold ~100 registers for the whole launch)
     int tid = threadIdx.x;
@@ -109,15 +122,20 @@ __device__ __forceinline__ bool stream_pass(const LstmPersistArgs& a, const Lstm
         // this wave's weight fragments of a batch: its gate's 16 columns x its K half (64 k) = 4 x 16 B per lane
         const size_t wrow = (size_t)(ut * 64 + gate * 16 + l15) * U_pad + kh * (LSTM_KB / 2) + 4 * lq;
         f32x4 wv[NBUF][LSTM_KS];
-        auto issue = [&](int b) {
+        auto issue_piece = [&](int b, int e) {   // one 1-KB piece (two rows) of activation tile b
             const float* src = (b < NBU ? up0 + b * LSTM_KB : lat0 + (b - NBU) * LSTM_KB);
             float* buf = ring + (b % NBUF) * BUF_FLOATS;
-#pragma unroll
-            for (int e = 0; e < NT; ++e)
-                __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(src + doff[e]), AM_LDS_PTR(buf + (wave + 8 * e) * 256), 16, 0, 16 /* sc1 */);
+            __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(src + doff[e]), AM_LDS_PTR(buf + (wave + 8 * e) * 256), 16, 0, 16 /* sc1 */);
+        };
+        auto issue_weights = [&](int b) {
             const float* wp = (b < NBU ? Ly.Wup + wrow + b * LSTM_KB : Ly.Wlat + wrow + (b - NBU) * LSTM_KB);
 #pragma unroll
             for (int s = 0; s < LSTM_KS; ++s) wv[b % NBUF][s] = *(const f32x4*)(wp + 16 * s);
+        };
+        auto issue = [&](int b) {
+#pragma unroll
+            for (int e = 0; e < NT; ++e) issue_piece(b, e);
+            issue_weights(b);
         };
         auto lat_wait = [&] { return stream_wait(a, a.counters + li, lat_target, s_flag); };   // step t - 1 of every workgroup of this layer
         // fragment addressing: row r*16 + l15, chunk (kh*16 + 4 s + lq) ^ l15
@@ -135,7 +153,11 @@ __device__ __forceinline__ bool stream_pass(const LstmPersistArgs& a, const Lstm
             __builtin_amdgcn_s_barrier();                                  // ... everybody's; and everyone has left tile b - 1
             const bool due = b + LEAD < NBT;
             if (due && NBL > 0 && NBU >= LEAD && b + LEAD == NBU) ok = lat_wait() && ok;
-            if (due) issue(b + LEAD);
+            // Few rows: the batch is a chain of latencies, the next stage is requested at once.  Many rows: every wave of the workgroup leaves the
+            // barrier at the same moment, and requested right there the NT LDS-DMA instructions of BOTH waves of a SIMD (~100-180 cycles each) find
+            // the matrix pipe idle; so the pieces go out between the MFMAs of the batch, K half 0's under sub-steps 0 and 1, K half 1's under 2 and 3.
+            constexpr bool SPREAD = NT >= 3;
+            if (due && !SPREAD) issue(b + LEAD);
             const float* sa = fbase + (b % NBUF) * BUF_FLOATS;
             f32x4 pb[NT];
 #pragma unroll
@@ -148,8 +170,24 @@ __device__ __forceinline__ bool stream_pass(const LstmPersistArgs& a, const Lstm
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < NT; ++r) pb[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][j], wv[b % NBUF][s][j], pb[r], 0, 0, 0);
+                    for (int r = 0; r < NT; ++r) {
+                        if constexpr (NT == 1) {
+                            // One row tile = ONE chain of 16 dependent MFMAs per batch, and that chain must accumulate IN PLACE (vDst = SrcC): written as
+                            // the builtin, hipcc (ROCm 7.2) gave the fourth MFMA of a sub-step a destination other than its SrcC and no wait states in
+                            // front of it -- v_mfma_f32_16x16x4_f32 v[10:13], v13, v17, v[38:41] right behind the MFMA that writes v[38:41] -- and rows
+                            // 8..15 of the product came out wrong (tools/lstm_forms_diff.py; every multi-tile instantiation interleaves independent chains and
+                            // is not affected).  In place the hardware forwards the running sum from one MFMA to the next.
+                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(pb[0]) : "v"(af[0][j]), "v"(wv[b % NBUF][s][j]));
+                        } else
+                        pb[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[r][j], wv[b % NBUF][s][j], pb[r], 0, 0, 0);
+                    }
+                if (due && SPREAD && (s >> 1) == kh) {   // (wave-uniform)
+#pragma unroll
+                    for (int e = 0; e < NT; ++e) if ((2 * e) / NT == (s & 1)) issue_piece(b + LEAD, e);
+                    if ((s & 1) == 1) issue_weights(b + LEAD);
+                }
             }
+            if constexpr (NT == 1) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the chain's last result must have left the matrix pipe before a vector instruction reads it
 #pragma unroll
             for (int r = 0; r < NT; ++r) {
                 acc[r] += pb[r];
@@ -160,6 +198,7 @@ __device__ __forceinline__ bool stream_pass(const LstmPersistArgs& a, const Lstm
         __syncthreads();   // every fragment read is done: the ring may be rewritten (gate exchange, next pass)
         if (!ok) return false;
     }
+    if (first_pass) stream_stamp(a, li, ut, t, 2);
 
     // gates.  thread = (row, 4 units): the four gates' upward terms (G rows of the stack's first layer, the bias otherwise), previous cell state
     float* sg = ring;   // [kh][gate][ROWS][STREAM_SGLD]
@@ -208,19 +247,15 @@ __device__ __forceinline__ bool stream_pass(const LstmPersistArgs& a, const Lstm
 
 template <int NBU, int NBL>
 __device__ __forceinline__ bool stream_pass_nt(int nt, const LstmPersistArgs& a, const LstmPersistLayer& Ly, int li, int ut, int t, int rows_valid, unsigned r_t, unsigned r_p,
-                                               unsigned lat_target, float* ring, int* s_flag)
+                                               unsigned lat_target, float* ring, int* s_flag, bool first_pass)
 {
     switch (nt) {   // uniform per workgroup
-    // (one row tile runs on the two-tile instantiation, its second tile's rows all clamped to the last valid one and never stored.  A one-tile
-    //  instantiation gave wrong sums for rows 8..15 of a step with both products -- every other tile count, and the one-tile form with a single
-    //  product, agree bit for bit with the per-step kernels; not understood (tools/dbg768.py reproduces it), so it is not instantiated.  A thin step is
-    //  bound by the 512 KB of weights it streams, not by its 2 x 16 MFMAs per batch.)
-    case 1:
-    case 2: return stream_pass<NBU, NBL, 2>(a, Ly, li, ut, t, rows_valid, r_t, r_p, lat_target, ring, s_flag);
-    case 3: return stream_pass<NBU, NBL, 3>(a, Ly, li, ut, t, rows_valid, r_t, r_p, lat_target, ring, s_flag);
-    case 4: return stream_pass<NBU, NBL, 4>(a, Ly, li, ut, t, rows_valid, r_t, r_p, lat_target, ring, s_flag);
-    case 5: return stream_pass<NBU, NBL, 5>(a, Ly, li, ut, t, rows_valid, r_t, r_p, lat_target, ring, s_flag);
-    case 6: return stream_pass<NBU, NBL, 6>(a, Ly, li, ut, t, rows_valid, r_t, r_p, lat_target, ring, s_flag);
+    case 1: return stream_pass<NBU, NBL, 1>(a, Ly, li, ut, t, rows_valid, r_t, r_p, lat_target, ring, s_flag, first_pass);
+    case 2: return stream_pass<NBU, NBL, 2>(a, Ly, li, ut, t, rows_valid, r_t, r_p, lat_target, ring, s_flag, first_pass);
+    case 3: return stream_pass<NBU, NBL, 3>(a, Ly, li, ut, t, rows_valid, r_t, r_p, lat_target, ring, s_flag, first_pass);
+    case 4: return stream_pass<NBU, NBL, 4>(a, Ly, li, ut, t, rows_valid, r_t, r_p, lat_target, ring, s_flag, first_pass);
+    case 5: return stream_pass<NBU, NBL, 5>(a, Ly, li, ut, t, rows_valid, r_t, r_p, lat_target, ring, s_flag, first_pass);
+    case 6: return stream_pass<NBU, NBL, 6>(a, Ly, li, ut, t, rows_valid, r_t, r_p, lat_target, ring, s_flag, first_pass);
     default: return true;
     }
 }
@@ -244,8 +279,10 @@ __global__ __launch_bounds__(512, 2) void lstm_stream_kernel(const LstmPersistAr
         n = n < 0 ? 0 : (n > a.slot_cap ? a.slot_cap : n);
         if (n <= 0) break;
         const unsigned off_t = (unsigned)a.step_off[t], off_p = t > 0 ? (unsigned)a.step_off[t - 1] : 0u;
+        stream_stamp(a, li, ut, t, 0);
         // the layer below has finished step t (it runs ahead: normally no wait at all)
         if (li > 0 && !stream_wait(a, a.counters + (li - 1), per_layer * (unsigned)(t + 1), s_flag)) return;
+        stream_stamp(a, li, ut, t, 1);
         const int tiles = (n + 15) >> 4, npass = (tiles + 5) / 6, q = (tiles + npass - 1) / npass;
         for (int p = 0; p < npass; ++p) {
             const int row0 = p * q * 16;
@@ -255,16 +292,18 @@ __global__ __launch_bounds__(512, 2) void lstm_stream_kernel(const LstmPersistAr
             const unsigned r_t = off_t + (unsigned)(a.slot_base + row0), r_p = off_p + (unsigned)(a.slot_base + row0);
             const unsigned lat_target = per_layer * (unsigned)t;
             bool ok;
-            if (upward) ok = t > 0 ? stream_pass_nt<NB, NB>(nt, a, Ly, li, ut, t, n - row0, r_t, r_p, lat_target, stream_smem, s_flag)
-                                   : stream_pass_nt<NB, 0>(nt, a, Ly, li, ut, t, n - row0, r_t, r_p, lat_target, stream_smem, s_flag);
-            else ok = t > 0 ? stream_pass_nt<0, NB>(nt, a, Ly, li, ut, t, n - row0, r_t, r_p, lat_target, stream_smem, s_flag)
-                            : stream_pass_nt<0, 0>(nt, a, Ly, li, ut, t, n - row0, r_t, r_p, lat_target, stream_smem, s_flag);
+            if (upward) ok = t > 0 ? stream_pass_nt<NB, NB>(nt, a, Ly, li, ut, t, n - row0, r_t, r_p, lat_target, stream_smem, s_flag, p == 0)
+                                   : stream_pass_nt<NB, 0>(nt, a, Ly, li, ut, t, n - row0, r_t, r_p, lat_target, stream_smem, s_flag, p == 0);
+            else ok = t > 0 ? stream_pass_nt<0, NB>(nt, a, Ly, li, ut, t, n - row0, r_t, r_p, lat_target, stream_smem, s_flag, p == 0)
+                            : stream_pass_nt<0, 0>(nt, a, Ly, li, ut, t, n - row0, r_t, r_p, lat_target, stream_smem, s_flag, p == 0);
             if (!ok) return;
         }
+        stream_stamp(a, li, ut, t, 4);
         // publish: every storing wave drains its stores, the workgroup meets, ONE lane signals for all of them
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_fetch_add(a.counters + li, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stream_stamp(a, li, ut, t, 6);
     }
 }
 

@@ -1,3 +1,11 @@
+#!/usr/bin/env python3
+"""Diagnostic: run one LSTM stack through the persistent form and through the per-step kernels on the same input and report the rows that differ
+(any difference is a bug: the forms are bit-equal by construction), with the oracle as referee on the utterances concerned.
+
+  python tools/lstm_forms_diff.py LAYERS UNITS [N_UTTS [N_LONG [BASE_LEN]]]      DBG_EXTRA=k: the N_LONG utterances are k frames longer (a thin tail)
+
+This is the tool that isolated round 4's one-tile miscompare (see stream_pass in csrc/am_lstm_stream.hip): rows 8..15 of every step with <= 16 active
+utterances, only with both products in the step -- a chain of dependent v_mfma_f32_16x16x4_f32 whose destination the compiler had not kept in place."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -21,7 +21,8 @@ def main():
     off = syn.make_offsets(rng, 192, N)
     x = rng.standard_normal((N, 40)).astype(np.float32)
     eng = Engine(0)
-    m = Model(eng, "lstm", 3, syn.make_lstm_params(rng, 40, 512, 3, 1909))
+    layers, units = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3, 512)   # (4 1024: the streamed form, one stamp row per layer)
+    m = Model(eng, "lstm", layers, syn.make_lstm_params(rng, 40, units, layers, 1909))
     p = Pipeline(eng)
     p.set_frontend(40, [0])
     p.set_members([m])
