@@ -358,7 +358,7 @@ def secondary_records(eng, ft, params, layers, x, steps):
         p.close()
         ml.close()
     # (iv b) the reference's own recurrent recipe shape (scripts/papers/specom2018/run.sh:9: "-n lstm -l 4 -u 1024 --timedelay 5"): its weights do not fit
-    # the register file, so it runs on the per-step kernels (one launch per (layer, time) diagonal)
+    # the register file; round 4: the streamed persistent form (lstm_stream_kernel, one launch, 256 workgroups), rounds 1-3: one launch per (layer, time) diagonal
     with _Guarded(out, "lstm_4x1024_td5") as g:
         rng = np.random.default_rng(SEED + 6)
         ml4 = g.own(Model(eng, "lstm", 4, make_lstm_params(rng, 40, 1024, 4, 1909)))
@@ -376,6 +376,24 @@ def secondary_records(eng, ft, params, layers, x, steps):
                                   "launches_per_pass": {k_: v[0] // k4 for k_, v in prof.items()}}
         p.close()
         ml4.close()
+    # (iv c) the other specom2018 recipe shape (run.sh:10: "-n gru -l 4 -u 1024 --timedelay 5"): per-step phase kernels, two dependent launches per tick
+    with _Guarded(out, "gru_4x1024_td5") as g:
+        rng = np.random.default_rng(SEED + 8)
+        mg4 = g.own(Model(eng, "gru", 4, make_gru_params(rng, 40, 1024, 4, 1909, reset_gate=True)))
+        p = g.own(Pipeline(eng))
+        p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
+        p.set_members([mg4])
+        p.lstm_upload(x[:n57], None, off, 5)
+        kq = 2
+        wall, _, prof = timed_runs(eng, p.lstm_run, kq, 1, pipe=p)
+        fl = 2 * (3 * (40 * 1024 + 3 * 1024 * 1024 + 4 * 1024 * 1024) + 1024 * 1909)
+        out["gru_4x1024_td5"] = {"value": n57 * kq / wall, "unit": "frames/s", "ms_per_pass": wall * 1e3 / kq, "frames": n57, "utterances": 192,
+                                 "roofline": {"bound": "mfma (dependent time steps)", "kernel": "whole pass", "achieved": fl * n57 * kq / wall / 1e12,
+                                              "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": fl * n57 * kq / wall / 1e12 / PEAK_F32_MFMA_TFLOPS},
+                                 "recurrent_form": "%d of %d members as one persistent launch" % p.recurrent_form(),
+                                 "launches_per_pass": {k_: v[0] // kq for k_, v in prof.items()}}
+        p.close()
+        mg4.close()
     # (v) BASELINE configs[4]: 10 fold members (4x1024 each), logits averaged on the device (evaluate.py:35-51) -- one GPU's share;
     # on a node the folds x utterances shard over the GPUs with no collective (sharding.py)
     with _Guarded(out, "ensemble_10x4x1024") as g:

@@ -49,7 +49,7 @@ hipError_t init_kernels();  // once per device after hipSetDevice
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
 
 // The Linear stack of one network as ONE launch: work queue over (layer, row tile, column tile), see gemm_stack_kernel.
-constexpr int GEMM_STACK_MAX_HIDDEN = 8;
+constexpr int GEMM_STACK_MAX_HIDDEN = 12;   // (the reference sweeps "ff -l 6..9", scripts/papers/tsd2018/run.sh:8-19)
 struct GemmStackLayer {
     const float* W; const float* bias; float* C;   // [N_pad, ldw], [N_pad], [M_pad, ldc]
     int ldw, ldc, tiles_n, nk;                     // column tiles (256 wide; output layer 256 or 192), K stages of 32

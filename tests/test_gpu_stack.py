@@ -43,7 +43,9 @@ def _stack_launches(engine, p, x, iv=None):
     (6, 2048, 100, 20001, 1909, "relu"),    # configs[2] shape, ragged
     (2, 512, 0, 4097, 1909, "sigmoid"),     # 17 row tiles, the last one row long
     (3, 256, 0, 777, 512, "tanh"),          # 256-wide output tiles; fewer items than workgroups (forced)
-    (8, 256, 0, 5000, 1909, "relu"),        # the deepest stack one launch takes
+    (8, 256, 0, 5000, 1909, "relu"),
+    (9, 512, 0, 9000, 1909, "relu"),        # the deepest feed-forward net the reference sweeps ("ff -l 9", scripts/papers/tsd2018/run.sh:17-19)
+    (12, 256, 0, 3000, 1909, "relu"),       # the deepest stack one launch takes
     (1, 768, 0, 300, 40, "relu"),           # one hidden layer, two row tiles
 ])
 def test_stack_equals_per_layer_launches(engine, real_ft_path, monkeypatch, layers, units, d_iv, n, n_out, act):
@@ -92,12 +94,12 @@ def test_stack_ensembles(engine, real_ft_path, real_priors, monkeypatch, master,
 
 
 def test_stack_not_taken(engine, real_ft_path, monkeypatch):
-    """Shapes outside the form stay on the per-layer launches: nine hidden layers, a hidden width that pads to 384."""
+    """Shapes outside the form stay on the per-layer launches: thirteen hidden layers, a hidden width that pads to 384."""
     rng = np.random.default_rng(9)
     ft = orc.load_kaldi_feature_transform(real_ft_path)
     x = rng.standard_normal((5000, 40)).astype(np.float32)
     monkeypatch.setenv("AM_FF_STACK", "2")
-    for layers, units in ((9, 256), (2, 300)):
+    for layers, units in ((13, 256), (2, 300)):
         params = orc.make_mlp_params(rng, 440, units, layers, 1909)
         p = _pipe(engine, [(layers, params)], ft, ft["shifts"])
         y, prof = _stack_launches(engine, p, x)
