@@ -5,8 +5,11 @@ import os
 import sys
 import time
 
+import warnings
+
 import numpy as np
 
+warnings.filterwarnings("ignore", category=RuntimeWarning)   # numpy's warnings about inf - inf / NaN in the poisoned cases: that is the point
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file lives in tests/)
 sys.path.insert(0, ROOT)
 from nnacousticmodeling_amd.engine import Engine, Model, Pipeline  # noqa: E402
@@ -70,6 +73,14 @@ def ensemble_case(eng, rng, it):
     return (float(np.max(np.abs(got - want))) if got.size else 0.0), desc
 
 
+def _poison(rng, x):
+    """Now and then a NaN value, a +inf value or a -inf value in the input (round 4): the device path must report what numpy reports."""
+    if x.shape[0] >= 3 and rng.random() < 0.12:
+        for v in rng.choice([np.nan, np.inf, -np.inf], int(rng.integers(1, 3))):
+            x[int(rng.integers(0, x.shape[0])), int(rng.integers(0, x.shape[1]))] = v
+    return x
+
+
 def one(eng, rng, ft_full, it):
     if rng.random() < 0.2:
         return ensemble_case(eng, rng, it)
@@ -84,8 +95,11 @@ def one(eng, rng, ft_full, it):
         n = int(rng.choice([1, 2, 63, 255, 256, 257, 1000, 3001, 6007]))   # 6007: above the 4096 padded rows from which a chunk may run as two row chains
         x = rng.standard_normal((n, D)).astype(np.float32)
         if kind == "ff":
+            x = _poison(rng, x)
             s = int(rng.choice([0, 1, 5]))
-            layers, units = int(rng.integers(0, 5)), int(rng.choice([8, 64, 100, 256, 300, 1024]))
+            layers, units = int(rng.choice([0, 1, 2, 3, 4, 4, 9, 12])), int(rng.choice([8, 64, 100, 256, 300, 1024]))   # (9, 12: deep stacks in one launch, round 4)
+            if layers > 4 and units == 1024:
+                units = 256
             act = str(rng.choice(["relu", "sigmoid", "tanh"]))
             shifts = list(range(-s, s + 1))
             add = (0.1 * rng.standard_normal(len(shifts) * D)).astype(np.float32)
@@ -133,10 +147,18 @@ def one(eng, rng, ft_full, it):
         n = int(offsets[-1])
         x = rng.standard_normal((n, D)).astype(np.float32)
         layers, units = int(rng.integers(1, 4)), int(rng.choice([8, 64, 96, 128, 200, 256, 512]))
+        if kind == "lstm" and rng.random() < 0.25:   # the streamed persistent form (round 4): 768 / 1024 units, up to 5 layers (two layer segments at 1024)
+            layers, units = int(rng.integers(1, 6)), int(rng.choice([768, 1024]))
+            if n_utts > 70:
+                n_utts = int(rng.choice([17, 33, 70])); lens = rng.integers(1, 60, n_utts)
+                offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64); n = int(offsets[-1])
+                x = rng.standard_normal((n, D)).astype(np.float32)
         td = int(rng.choice([0, 0, 2, 5]))
         add = (0.1 * rng.standard_normal(D)).astype(np.float32)
         scale = rng.uniform(0.5, 1.5, D).astype(np.float32)
         ft = {"shape": [D, D], "shifts": [0], "addShift": add, "rescale": scale}
+        if kind == "lstm":
+            x = _poison(rng, x)
         if kind in ("lstm", "peepholelstm"):
             params = (orc.make_peephole_params if kind == "peepholelstm" else orc.make_lstm_params)(rng, D, units, layers, C)
         else:
@@ -151,6 +173,14 @@ def one(eng, rng, ft_full, it):
         p.set_members([Model(eng, kind, layers, params)])
         p.set_prior(prior)
         got = p.forward_lstm(x, offsets, timedelay=td)
+    if got.size and not np.isfinite(want).all():
+        # poisoned input (below): the non-finite classes must agree element by element, the finite rows within the tolerance
+        same = (np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isposinf(got), np.isposinf(want)) and np.array_equal(np.isneginf(got), np.isneginf(want)))
+        fin = np.isfinite(want)
+        err = (float(np.max(np.abs(got[fin] - want[fin]))) if fin.any() else 0.0) if same else float("inf")
+        desc["nonfinite_rows"] = int((~np.isfinite(want).all(axis=1)).sum())
+        p.close()
+        return err, desc
     err = float(np.max(np.abs(got - want))) if got.size else 0.0
     p.close()
     if not (err <= TOL) and kind not in ("ff", "tdnn"):
