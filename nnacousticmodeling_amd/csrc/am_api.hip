@@ -980,7 +980,7 @@ static int tdnn_member_forward(am_pipeline* p, int mi, int64_t frames, float* ac
         if (l < m->n_layers) {
             g.M_pad = (int)round_up(frames * m->pos[l + 1], GEMM_BM);
             g.row_p = m->pos[l + 1]; g.row_skip = m->ksize[l] - 1;
-            g.C = ((l & 1) ? p->d_act1 : p->d_act0).as<float>(); g.ldc = Ly.out_pad; g.epi = EPI_ACT; g.alpha = 1.f;
+            g.C = ((l & 1) ? p->d_act1 : p->d_act0).as<float>(); g.ldc = Ly.out_pad; g.epi = EPI_ACT; g.alpha = 1.f; g.n_real = Ly.out;
             id = K_GEMM_HIDDEN;
         } else {
             g.M_pad = (int)round_up(frames, GEMM_BM);   // pos[n_layers] == 1: one row per frame
@@ -1037,7 +1037,9 @@ static int ff_stack_mode() { return (int)env_int("AM_FF_STACK", 1); }   // read 
 static bool ff_stack_shape_ok(const am_model* m)
 {
     if (m->tdnn || m->n_layers < 1 || m->n_layers > GEMM_STACK_MAX_HIDDEN) return false;
-    for (int l = 0; l < m->n_layers; ++l) if (m->L[l].out_pad % 256 || m->L[l].in_pad % 32) return false;
+    // (hidden widths that need padding stay on the per-layer launches: their epilogue forces the pad columns to 0, which this kernel has no registers for --
+    //  an infinite input value would otherwise become inf x 0 = NaN there and spread; every width of the reference's recipes is a multiple of 256)
+    for (int l = 0; l < m->n_layers; ++l) if (m->L[l].out_pad % 256 || m->L[l].in_pad % 32 || m->L[l].out != m->L[l].out_pad) return false;
     const Layer& out = m->L[m->n_layers];
     return out.out_pad % 256 == 0 || out.out_pad % 192 == 0;
 }
@@ -1182,7 +1184,7 @@ static int ff_member_forward(am_pipeline* p, int mi, int64_t rows_pad, float* ac
         g.M_pad = (int)rows_pad; g.N_pad = Ly.out_pad; g.K_pad = Ly.in_pad; g.act = m->act;
         int id;
         if (l < m->n_layers) {
-            g.C = ((l & 1) ? p->d_act1 : p->d_act0).as<float>() + row0 * Ly.out_pad; g.ldc = Ly.out_pad; g.epi = EPI_ACT; g.alpha = 1.f;
+            g.C = ((l & 1) ? p->d_act1 : p->d_act0).as<float>() + row0 * Ly.out_pad; g.ldc = Ly.out_pad; g.epi = EPI_ACT; g.alpha = 1.f; g.n_real = Ly.out;
             id = K_GEMM_HIDDEN;
         } else {
             g.C = acc; g.ldc = m->C_pad; g.epi = epilogue_mode(p, mi, &g.alpha);
@@ -1751,7 +1753,7 @@ static int rec_stack(am_pipeline* p, am_model* m, size_t h_stride)
     for (int64_t d = 0; d < T + NL - 1; ++d)
         for (int ph = 0; ph < phases; ++ph) {
             RecStepArgs w{};
-            w.U_pad = U_pad; w.act = m->act;
+            w.U_pad = U_pad; w.act = m->act; w.U_real = m->L[0].U;
             int epi = REC_MGRU;
             for (int l = 0; l < NL; ++l) {
                 const int64_t t = d - l;
@@ -1851,6 +1853,7 @@ static int lstm_enqueue(am_pipeline* p)
             // both sides, so the product stops at the GEMM's own k step (40 inputs: 64 instead of 128 -- half the launch, the same bits)
             g.K_pad = std::min(L0.in_pad, (int)round_up(L0.in, GEMM_BK));
             g.epi = EPI_LINEAR; g.alpha = 1.f;
+            g.tiled_units = L0.U;   // pad units' rows of G stay 0 whatever the input holds (inf x 0 would be NaN and spread through the lateral product)
             AM_TRY(run_kernel(e, K_LSTM_UPWARD, [&] { return launch_gemm(e->stream, g); }));
         }
         float* Hall = p->d_H.as<float>();

@@ -63,7 +63,9 @@ __global__ __launch_bounds__(512) void rec_step_kernel(const RecStepArgs args)
     constexpr int ITEMS = 16 * NU;                          // per row tile
     const int er = tid / ITEMS, erow = (tid % ITEMS) / NU, euu = tid % NU;
     const int eslot = row0 + er * 16 + erow;
-    const bool elive = tid < ITEMS * R && er < ntile && eslot < n_active;
+    // (pad units -- their weights and bias are zero -- are never stored: their planes keep the zeros of the upload.  Computed, an infinite input value would
+    //  make them inf x 0 = NaN, which the next product spreads into every real unit; see gemm_epilogue)
+    const bool elive = tid < ITEMS * R && er < ntile && eslot < n_active && tile * NU + euu < args.U_real;
     const size_t eidx = (size_t)eslot * U_pad + tile * NU + euu;
     float bias[G], e0 = 0.0f, e1 = 0.0f;
 #pragma unroll
@@ -147,7 +149,7 @@ constexpr int REC_WIDE_ROWS = 64;
 constexpr size_t REC_WIDE_LDS = 2 * REC_WIDE_ROWS * LSTM_LDA * sizeof(float);   // 67,584 B; the exchange buffer aliases it
 
 template <int G, int EPI, int NT, bool ZW>   // ZW: the batch count is not a multiple of the 4-slot rotation (zero weights past the end)
-__device__ __forceinline__ void rec_wide_body(const RecLayerStep& Ls, int U_pad, int act, int bt, int row0, float* smem)
+__device__ __forceinline__ void rec_wide_body(const RecLayerStep& Ls, int U_pad, int U_real, int act, int bt, int row0, float* smem)
 {
     constexpr int NU = 16 / G, UB = 4 * NU;               // units per column tile / per block
     constexpr int ROWS = NT * 16;
@@ -254,7 +256,7 @@ __device__ __forceinline__ void rec_wide_body(const RecLayerStep& Ls, int U_pad,
 #pragma unroll
     for (int e = 0; e < EP; ++e) {
         const int idx = tid + 512 * e, erow = idx / UB, ub = idx % UB, slot = row0 + erow;
-        if (erow < ROWS && slot < n_active) {
+        if (erow < ROWS && slot < n_active && bt * UB + ub < U_real) {   // (pad units are never stored: rec_step_kernel)
             const int ct = ub / NU, uu = ub % NU;
             float pre[G];
 #pragma unroll
@@ -284,18 +286,18 @@ __global__ __launch_bounds__(512, 2) void rec_wide_kernel(const RecStepArgs args
     const bool zw = (((Ls.K[0] + Ls.K[1] + Ls.K[2]) / LSTM_KB) & 3) != 0;   // uniform per block
     if (zw) {
         switch (ntile) {
-        case 1: rec_wide_body<G, EPI, 1, true>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
-        case 2: rec_wide_body<G, EPI, 2, true>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
-        case 3: rec_wide_body<G, EPI, 3, true>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
-        case 4: rec_wide_body<G, EPI, 4, true>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
+        case 1: rec_wide_body<G, EPI, 1, true>(Ls, U_pad, args.U_real, args.act, bt, row0, rec_wide_smem); break;
+        case 2: rec_wide_body<G, EPI, 2, true>(Ls, U_pad, args.U_real, args.act, bt, row0, rec_wide_smem); break;
+        case 3: rec_wide_body<G, EPI, 3, true>(Ls, U_pad, args.U_real, args.act, bt, row0, rec_wide_smem); break;
+        case 4: rec_wide_body<G, EPI, 4, true>(Ls, U_pad, args.U_real, args.act, bt, row0, rec_wide_smem); break;
         default: break;
         }
     } else {
         switch (ntile) {
-        case 1: rec_wide_body<G, EPI, 1, false>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
-        case 2: rec_wide_body<G, EPI, 2, false>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
-        case 3: rec_wide_body<G, EPI, 3, false>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
-        case 4: rec_wide_body<G, EPI, 4, false>(Ls, U_pad, args.act, bt, row0, rec_wide_smem); break;
+        case 1: rec_wide_body<G, EPI, 1, false>(Ls, U_pad, args.U_real, args.act, bt, row0, rec_wide_smem); break;
+        case 2: rec_wide_body<G, EPI, 2, false>(Ls, U_pad, args.U_real, args.act, bt, row0, rec_wide_smem); break;
+        case 3: rec_wide_body<G, EPI, 3, false>(Ls, U_pad, args.U_real, args.act, bt, row0, rec_wide_smem); break;
+        case 4: rec_wide_body<G, EPI, 4, false>(Ls, U_pad, args.U_real, args.act, bt, row0, rec_wide_smem); break;
         default: break;
         }
     }

@@ -22,9 +22,13 @@ namespace am {
 
 // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 // MODE: 0 relu, 1 sigmoid, 2 tanh, 3 linear, 4 scale by alpha, 5 accumulate into C.
+// Pad columns (col >= n_real; gate-tiled layouts: unit 16 (col / 64) + col % 16 >= tiled_units) of an activation / linear output are forced to 0.
+// Their weights and bias are zero, so they ARE zero for finite inputs -- but an infinite input value makes them inf x 0 = NaN, and the next layer would
+// multiply that NaN by its own zero pad weights into every real column, where the reference (which has no padding) stays finite (sigmoid / tanh
+// layers, LSTM gates saturate on an infinite pre-activation).  Found by the round-4 fuzz (tests/fuzz_gpu.py, tools/nonfinite_probe.py).
 template <int MODE, int MI, int NI>
 __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NI], const float* __restrict__ bias, float* __restrict__ C,
-                                              int ldc, int erow, int ecol, float alpha)
+                                              int ldc, int erow, int ecol, float alpha, int n_real, int tiled_units)
 {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -32,6 +36,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NI], const
         for (int ni = 0; ni < NI; ++ni) {
             const int col = ecol + ni * 32;
             const float bv = bias[col];
+            const bool padc = MODE <= 3 && (tiled_units > 0 ? 16 * (col >> 6) + (col & 15) >= tiled_units : col >= n_real);
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = erow + mi * 32 + (reg & 3) + 8 * (reg >> 2);
@@ -42,6 +47,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NI], const
                 else if (MODE == 2) v = tanhf(v);
                 else if (MODE == 4) v = v * alpha;
                 else if (MODE == 5) v = *dst + v;
+                if (padc) v = 0.0f;
                 *dst = v;
             }
         }
@@ -155,7 +161,7 @@ __device__ __forceinline__ void gemm_tile_products(const float* __restrict__ A, 
 
 template <int BN>
 __device__ __forceinline__ void gemm_tile_epilogue(const f32x16 (&acc)[GEMM_BM / GEMM_WM / 32][BN / GEMM_WN / 32], const float* __restrict__ bias,
-                                                   float* __restrict__ C, int ldc, int m0, int n0, int act, int epi, float alpha)
+                                                   float* __restrict__ C, int ldc, int m0, int n0, int act, int epi, float alpha, int n_real, int tiled_units)
 {
     constexpr int MI = GEMM_BM / GEMM_WM / 32, NI = BN / GEMM_WN / 32;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -163,18 +169,19 @@ __device__ __forceinline__ void gemm_tile_epilogue(const f32x16 (&acc)[GEMM_BM /
     // one uniform dispatch on the mode, then straight-line code
     const int erow = m0 + wm * (GEMM_BM / GEMM_WM) + 4 * lh, ecol = n0 + wn * (BN / GEMM_WN) + li;
     if (epi == EPI_ACT) {
-        if (act == 0) gemm_epilogue<0, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
-        else if (act == 1) gemm_epilogue<1, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
-        else gemm_epilogue<2, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
-    } else if (epi == EPI_LINEAR) gemm_epilogue<3, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
-    else if (epi == EPI_SCALE) gemm_epilogue<4, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
-    else gemm_epilogue<5, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha);
+        if (act == 0) gemm_epilogue<0, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha, n_real, tiled_units);
+        else if (act == 1) gemm_epilogue<1, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha, n_real, tiled_units);
+        else gemm_epilogue<2, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha, n_real, tiled_units);
+    } else if (epi == EPI_LINEAR) gemm_epilogue<3, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha, n_real, tiled_units);
+    else if (epi == EPI_SCALE) gemm_epilogue<4, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha, n_real, tiled_units);
+    else gemm_epilogue<5, MI, NI>(acc, bias, C, ldc, erow, ecol, alpha, n_real, tiled_units);
 }
 
 template <int BN, int BK>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, const float* __restrict__ bias,
-    float* __restrict__ C, int ldc, int tiles_n, int nk, int act, int epi, float alpha, int row_p, int row_skip, int* __restrict__ queue, int n_tiles)
+    float* __restrict__ C, int ldc, int tiles_n, int nk, int act, int epi, float alpha, int row_p, int row_skip, int* __restrict__ queue, int n_tiles,
+    int n_real, int tiled_units)
 {
     constexpr int BM = GEMM_BM;
     constexpr int MI = BM / GEMM_WM / 32, NI = BN / GEMM_WN / 32;
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32_kernel(
     const int m0 = tm * BM, n0 = tn * BN;
     f32x16 acc[MI][NI];
     gemm_tile_products<BN, BK, 0, false>(A, lda, W, ldw, m0, n0, nk, row_p, row_skip, smem, acc);
-    gemm_tile_epilogue<BN>(acc, bias, C, ldc, m0, n0, act, epi, alpha);
+    gemm_tile_epilogue<BN>(acc, bias, C, ldc, m0, n0, act, epi, alpha, n_real, tiled_units);
     if (!queue) break;
     }
 }
@@ -251,19 +258,19 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g)
         const int tiles_n = g.N_pad / 256, n_tiles = tiles_m * tiles_n;
         const int grid = g.queue ? std::min(n_tiles, g.n_cus) : n_tiles;     // work-queue mode: one block per CU slot is enough
         hipLaunchKernelGGL((gemm_nt_f32_kernel<256, 32>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_256, s,
-                           g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 32, g.act, g.epi, g.alpha, g.row_p, g.row_skip, g.queue, n_tiles);
+                           g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 32, g.act, g.epi, g.alpha, g.row_p, g.row_skip, g.queue, n_tiles, g.n_real, g.tiled_units);
     } else if (g.N_pad % 192 == 0 && !getenv("AM_GEMM_384")) {
         // 1909 classes -> 1920 = 10 x 192: half the tile of the 384-wide form (the round-1 choice, kept behind AM_GEMM_384 for A/B runs) --
         // 96 accumulator registers instead of 192, no spills, and twice as many tiles to fill the last round of a launch with
         const int tiles_n = g.N_pad / 192, n_tiles = tiles_m * tiles_n;
         const int grid = g.queue ? std::min(n_tiles, g.n_cus) : n_tiles;
         hipLaunchKernelGGL((gemm_nt_f32_kernel<192, 32>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_192, s,
-                           g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 32, g.act, g.epi, g.alpha, g.row_p, g.row_skip, g.queue, n_tiles);
+                           g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 32, g.act, g.epi, g.alpha, g.row_p, g.row_skip, g.queue, n_tiles, g.n_real, g.tiled_units);
     } else if (g.N_pad % 384 == 0) {
         const int tiles_n = g.N_pad / 384, n_tiles = tiles_m * tiles_n;
         const int grid = g.queue ? std::min(n_tiles, 2 * g.n_cus) : n_tiles;
         hipLaunchKernelGGL((gemm_nt_f32_kernel<384, 16>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_384, s,
-                           g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 16, g.act, g.epi, g.alpha, g.row_p, g.row_skip, g.queue, n_tiles);
+                           g.A, g.lda, g.W, g.ldw, g.bias, g.C, g.ldc, tiles_n, g.K_pad / 16, g.act, g.epi, g.alpha, g.row_p, g.row_skip, g.queue, n_tiles, g.n_real, g.tiled_units);
     } else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -294,6 +301,8 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g)
 // 256 x 256 tile (the whole headline pass 3.3 % slower than with plain stores).  So the block goes through LDS once and leaves
 // as whole lines -- a wave's 64 x 128 block as 2 rows x 512 B per store instruction -- which costs the same as plain stores.
 // Each wave stages 32 rows x 128 columns at a time in its own 17-KB slice (row stride 136 floats: conflict-free b128 writes).
+// (No pad-column mask here -- it costs this kernel 9 registers it does not have (256 + scratch): the host only takes this form for hidden widths that
+//  need no padding, ff_stack_shape_ok; padded widths run one launch per layer, whose epilogue masks: gemm_epilogue.)
 constexpr int GEMM_STACK_STAGE_LD = 136;
 constexpr int GEMM_STACK_LDS = (GEMM_WM * GEMM_WN) * 32 * GEMM_STACK_STAGE_LD * 4;   // 139,264 B >= the products' two stages
 // MODE: 0 relu, 1 sigmoid, 2 tanh (hidden layers, stored write-through: AUX = 16); 5 accumulate into C (an ensemble's second and later
@@ -454,7 +463,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_stack_kernel(const GemmS
             } else {
                 gemm_tile_products<BN, BK, 16, false>(A, lda, Ly.W, Ly.ldw, m0, n0, Ly.nk, 0, 0, smem, acc, hook);
                 phase(2);
-                gemm_tile_epilogue<BN>(acc, Ly.bias, Ly.C, Ly.ldc, m0, n0, a.act, a.out_epi, a.out_alpha);   // plain stores: read by later launches only
+                gemm_tile_epilogue<BN>(acc, Ly.bias, Ly.C, Ly.ldc, m0, n0, a.act, a.out_epi, a.out_alpha, 1 << 30, 0);   // plain stores: read by later launches only
             }
             phase(3);
         }

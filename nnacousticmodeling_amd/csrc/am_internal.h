@@ -42,6 +42,8 @@ struct GemmArgs {
     int act;                      // AM_ACT_* (EPI_ACT only)
     int epi; float alpha;
     int row_p = 0, row_skip = 0;  // TDNN: output row R reads A row R + (R / row_p) * row_skip (0 = plain GEMM)
+    int n_real = 1 << 30;         // EPI_ACT / EPI_LINEAR: output columns >= n_real are padding and are forced to 0 (an infinite input must not turn them into NaN)
+    int tiled_units = 0;          // > 0: the output is gate-tiled (LSTM: column -> unit 16 (col / 64) + col % 16) and units >= tiled_units are padding
     int* queue = nullptr;         // work-queue mode: device counter (zero before the launch) the blocks pull tile numbers from
     int n_cus = 256;              // work-queue mode: CUs of the device (grid = one block per CU)
 };
@@ -214,6 +216,7 @@ struct RecLayerStep {
 struct RecStepArgs {
     RecLayerStep L[LSTM_MAX_LAYERS];
     int n; int U_pad; int act;     // act: AM_ACT_* of the candidate state (GRU: tanh, MGRU-relu: relu)
+    int U_real;                    // units >= U_real are padding: their outputs are forced to 0 (see gemm_epilogue)
     int bt_groups;                 // set by the launcher of rec_wide_kernel
 };
 hipError_t launch_rec_step(hipStream_t s, int epilogue, const RecStepArgs& a);

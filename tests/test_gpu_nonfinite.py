@@ -163,3 +163,48 @@ def test_rpl4_floor_and_log_softmax_propagate_nan(engine, real_ft_path, real_pri
     bad_rows = ~np.isfinite(want).all(axis=1)
     assert bad_rows.sum() == 22 and np.isnan(got[bad_rows]).all()
     assert np.max(np.abs(got[~bad_rows] - want[~bad_rows])) <= TOL
+
+
+@pytest.mark.parametrize("kind,units,act", [("ff", 100, "sigmoid"), ("ff", 64, "tanh"), ("ff", 300, "sigmoid"), ("lstm", 96, None), ("lstm", 64, None),
+                                            ("gru", 72, None), ("mgrurelu", 40, None), ("peepholelstm", 100, None)])
+def test_padded_widths_do_not_turn_inf_into_nan(engine, kind, units, act):
+    """Widths that are padded on the device (hidden widths to 256 / 384, recurrent widths to 64 / 128) have pad columns whose weights are zero.  An infinite
+    input value times a zero pad weight is NaN, and the next product would spread that NaN into every real column -- while the reference, which has no
+    padding, stays finite wherever an infinite pre-activation only saturates a sigmoid / tanh / gate.  The pad columns are therefore forced to 0
+    (gemm_epilogue, the LSTM's hoisted projection) or never stored (the other cells).  Found by tests/fuzz_gpu.py in round 4."""
+    from nnacousticmodeling_amd.engine import Model, Pipeline
+    rng = np.random.default_rng(len(kind) * 1000 + units)
+    D, C = 40, 39
+    add = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, D).astype(np.float32)
+    ft = {"shape": [D, D], "shifts": [0], "addShift": add, "rescale": scale}
+    p = Pipeline(engine)
+    p.set_frontend(D, [0], add, scale, 0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if kind == "ff":
+            params = orc.make_mlp_params(rng, D, units, 3, C)
+            x = rng.standard_normal((300, D)).astype(np.float32)
+            x[100, 3] = np.inf
+            x[200, 30] = -np.inf
+            want = np.concatenate(orc.evaluate_posteriors(orc.MLP(params, 3, act), orc.evaluate_frontend(x, 0, ft), np.array([0, 300])))
+            p.set_members([Model(engine, "ff", 3, params, act)])
+            got = p.forward_ff(x)
+        else:
+            layers = 2
+            params = (orc.make_lstm_params if kind == "lstm" else orc.make_peephole_params if kind == "peepholelstm" else orc.make_gru_params)(
+                rng, D, units, layers, C, **({"reset_gate": kind == "gru"} if kind in ("gru", "mgrurelu") else {}))
+            lens = np.array([40, 33, 30, 21])
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            x = rng.standard_normal((int(off[-1]), D)).astype(np.float32)
+            x[45, 7] = np.inf
+            x[80, 1] = -np.inf
+            want = orc.predict(orc.get_nn(kind, layers, params), x, off, True, 1, 0, ft)
+            p.set_members([Model(engine, kind, layers, params)])
+            got = p.forward_lstm(x, off)
+    _same_nonfinite(got, want)
+    fin = np.isfinite(want)
+    assert fin.any() and np.max(np.abs(got[fin] - want[fin])) <= TOL
+    if kind != "mgrurelu" and act != "relu":
+        assert np.isfinite(want).all()      # saturating non-linearities everywhere: the reference stays finite, and so must the device
+    p.close()
