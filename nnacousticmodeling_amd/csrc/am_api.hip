@@ -161,6 +161,7 @@ struct am_pipeline {
     // lstm
     DevBuf d_src, d_dst, d_G, d_H, d_c;   // d_H / d_c: one packed H plane and one cell-state array per layer
     DevBuf d_cplane;                      // persistent form: the cell state as one time-major packed plane per layer, like d_H
+    DevBuf d_recplanes;                   // persistent form of the other cells: two more time-major planes per layer (GRU: Z, r.h; peephole: c, the o pre-activation)
     std::vector<int64_t> step_off;
     std::vector<int> n_active;
     int64_t n_packed = 0;
@@ -172,7 +173,10 @@ struct am_pipeline {
         std::vector<LstmPersistArgs> chunks;   // one launch per (layer segment, chunk of utterance slots); utterances are independent, longest first
         std::vector<int> layer0;               // the model layer that is L[0] of chunks[i] (a deep stack runs as several launches over layer ranges)
         std::vector<DevBuf> cums;
-        void release() { for (auto& c : cums) c.release(); cums.clear(); chunks.clear(); layer0.clear(); form = 0; }
+        RecStreamArgs rsa{};                   // form 3: the cells' persistent launch (rec_stream_kernel) and its role table on the device
+        DevBuf d_roles;
+        std::vector<RecStreamRole> h_roles;    // (the host copy the asynchronous upload reads from: lives as long as the plan)
+        void release() { for (auto& c : cums) c.release(); cums.clear(); chunks.clear(); layer0.clear(); d_roles.release(); form = 0; }
     };
     std::vector<PersistPlan> persist;
     DevBuf d_nact, d_stepoff, d_sync;   // int [T], int [T + 1], unsigned [groups + 1] (arrival counters, abort flag last)
@@ -793,7 +797,7 @@ extern "C" int am_pipeline_destroy(am_pipeline* p)
     for (auto ev : p->ev_chain) if (ev) (void)hipEventDestroy(ev);
     p->drop_graph();
     for (DevBuf* d : {&p->d_shifts, &p->d_add, &p->d_scale, &p->d_rplw, &p->d_rplb, &p->d_rpllb, &p->d_prior, &p->d_x, &p->d_ivec, &p->d_in, &p->d_in_s,
-                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_stack, &p->d_ffsync, &p->d_stack2, &p->d_ffsync2, &p->d_accs, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c, &p->d_cplane, &p->d_nact, &p->d_stepoff, &p->d_sync, &p->d_stamps})
+                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_stack, &p->d_ffsync, &p->d_stack2, &p->d_ffsync2, &p->d_accs, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c, &p->d_cplane, &p->d_recplanes, &p->d_nact, &p->d_stepoff, &p->d_sync, &p->d_stamps})
         d->release();
     for (auto& pl : p->persist) pl.release();
     am_engine* e = p->e;
@@ -1564,7 +1568,7 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
     p->persist.clear();
     p->persist.resize(p->members.size());
     const int pmode = lstm_persist_mode();
-    bool any_persist = false;
+    bool any_persist = false, any_recstream = false;
     if (pmode && !gate_of(e).off.load() && T > 0 && (size_t)rows_alloc * gw * sizeof(float) < ((size_t)1 << 31)) {
         std::vector<int> nact(p->n_active.begin(), p->n_active.end()), soff(p->step_off.begin(), p->step_off.end());
         AM_TRY(p->d_nact.ensure(sizeof(int) * nact.size()));
@@ -1575,7 +1579,29 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
         std::vector<std::vector<unsigned>> staging;   // alive until the copies below have been synchronised
         for (size_t mi = 0; mi < p->members.size(); ++mi) {
             am_model* m = p->members[mi];
-            if (m->cell != AM_CELL_LSTM) continue;
+            if (m->cell != AM_CELL_LSTM) {
+                // GRU / MGRU / peephole stacks: the persistent form (rec_stream_kernel) when its row groups fill the chip -- at least two groups, or a
+                // file of at most four row tiles; otherwise (1024-unit stacks: one group of 192 workgroups would take every row in three passes) the
+                // per-tick phase kernels.  AM_REC_STREAM=0 never, 2 whenever it fits.
+                static const int64_t rs_mode = env_int("AM_REC_STREAM", 1);
+                const int n_phase = m->cell == AM_CELL_MGRU ? 1 : 2;
+                const int U_pad = m->L[0].U_pad, NL = m->n_layers;
+                const int ncA = (m->cell == AM_CELL_PEEPHOLE ? 4 : 2) * U_pad / 64, ncB = U_pad / 64;
+                const int per_group = NL * (ncA + (n_phase == 2 ? ncB : 0));
+                const int swgs = rs_mode ? rec_stream_resident_wgs(e->n_cus) : 0;
+                const int tiles = (n_utts + 15) / 16;
+                int NG = per_group > 0 ? swgs / per_group : 0;
+                NG = std::min(NG, std::max(tiles, 1));
+                while (NG > 0 && NL * n_phase * NG > 62) --NG;   // arrival counters: d_sync holds 63
+                if (NG < 1 || NL * n_phase > RS_MAX_ROLES || (rs_mode != 2 && NG < 2 && tiles > 4)) continue;
+                auto& pl = p->persist[mi];
+                RecStreamArgs& ra = pl.rsa;
+                ra = RecStreamArgs{};
+                ra.n_roles = NL * n_phase; ra.NG = NG; ra.wgs_per_group = per_group; ra.T = (int)T; ra.U_pad = U_pad; ra.U_real = m->L[0].U; ra.act = m->act; ra.max_wgs = swgs;
+                AM_TRY(pl.d_roles.ensure(sizeof(RecStreamRole) * RS_MAX_ROLES));
+                pl.form = 3; any_persist = true; any_recstream = true;
+                continue;
+            }
             bool fits = m->L[0].out_pad == 4 * m->L[0].U_pad;
             for (int l = 0; l < m->n_layers && fits; ++l) fits = m->L[l].U_pad == m->L[0].U_pad && (l == 0 || m->L[l].in_pad == m->L[l].U_pad);
             if (!fits) continue;
@@ -1649,6 +1675,10 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
         AM_TRY(sync_all(e));   // the staging vectors go out of scope here
     }
     if (any_persist) AM_TRY(p->d_cplane.ensure(sizeof(float) * rows_alloc * upad * max_layers));   // written before it is read: no memset
+    if (any_recstream) {   // pad units are never stored: their columns must read as zeros
+        AM_TRY(p->d_recplanes.ensure(sizeof(float) * 2 * rows_alloc * upad * max_layers));
+        HIP_TRY(hipMemsetAsync(p->d_recplanes.p, 0, sizeof(float) * 2 * rows_alloc * upad * max_layers, e->stream));
+    }
     AM_TRY(sync_all(e));
     p->drop_graph();
     p->n = N; p->n_packed = NP; p->n_slots = n_utts; p->has_ivec = ivec != nullptr; p->timedelay = timedelay;
@@ -1809,6 +1839,86 @@ static int rec_stack(am_pipeline* p, am_model* m, size_t h_stride)
     return AM_OK;
 }
 
+// The same stack as ONE persistent launch (rec_stream_kernel): roles = phases of layers, planes time-major and written once.
+static int rec_stack_stream(am_pipeline* p, int mi, size_t h_stride)
+{
+    am_engine* e = p->e;
+    am_model* m = p->members[mi];
+    auto& pl = p->persist[mi];
+    RecStreamArgs ra = pl.rsa;
+    const int NL = m->n_layers, U_pad = ra.U_pad, nbu = U_pad / LSTM_KB;
+    const int n_phase = m->cell == AM_CELL_MGRU ? 1 : 2;
+    const int ncA = (m->cell == AM_CELL_PEEPHOLE ? 4 : 2) * U_pad / 64, ncB = U_pad / 64;
+    float* Hall = p->d_H.as<float>();
+    float* X = p->d_recplanes.as<float>();
+    std::vector<RecStreamRole>& roles = pl.h_roles;
+    roles.assign(ra.n_roles, RecStreamRole{});
+    int wg = 0;
+    for (int l = 0; l < NL; ++l) {
+        Layer& Ly = m->L[l];
+        float* H = Hall + l * h_stride;
+        float* P1 = X + (size_t)(2 * l) * h_stride; float* P2 = X + (size_t)(2 * l + 1) * h_stride;
+        const int rA = n_phase * l, rB = n_phase * l + 1;
+        const int below = l > 0 ? n_phase * (l - 1) + (n_phase - 1) : -1;       // the role that writes h of the layer below
+        const unsigned below_mult = (unsigned)(n_phase == 1 ? ncA : ncB);
+        RecStreamSeg sx{};   // the cell's input: the gathered frames (layer 0) or h of the layer below at the same step
+        sx.A = l == 0 ? p->d_in.as<float>() : Hall + (l - 1) * h_stride; sx.ld = l == 0 ? m->in_pad : U_pad; sx.nb = Ly.Kx / LSTM_KB;
+        sx.prev = 0; sx.skip_first = 0; sx.dep = below; sx.dep_mult = below_mult;
+        RecStreamSeg none{}; none.dep = -1;
+        RecStreamRole& A = roles[rA];
+        A = RecStreamRole{};
+        A.seg[0] = sx; A.seg[1] = none; A.seg[2] = none;
+        A.n_col = ncA; A.wg0 = wg; A.counter = rA; A.edep = -1; wg += ncA;
+        const int hw = n_phase == 1 ? rA : rB;                                   // the role that writes this layer's h
+        RecStreamSeg sh{};   // h of this layer at the previous step
+        sh.A = H; sh.ld = U_pad; sh.nb = nbu; sh.prev = 1; sh.skip_first = 1; sh.dep = hw; sh.dep_mult = (unsigned)(n_phase == 1 ? ncA : ncB);
+        if (m->cell == AM_CELL_MGRU) {
+            A.seg[1] = sh; A.W = Ly.WA.as<float>(); A.ldw = Ly.Kx + U_pad;
+            A.bias_first = Ly.bA_first.as<float>(); A.bias_rest = Ly.bA_rest.as<float>();
+            A.E0 = H; A.O0 = H; A.epi = REC_MGRU;
+            continue;
+        }
+        RecStreamRole& B = roles[rB];
+        B = RecStreamRole{};
+        B.seg[0] = sx; B.seg[1] = none; B.seg[2] = none;
+        B.n_col = ncB; B.wg0 = wg; B.counter = rB; B.edep = -1; wg += ncB;
+        if (m->cell == AM_CELL_GRU) {
+            A.seg[1] = sh; A.W = Ly.WA.as<float>(); A.ldw = Ly.Kx + U_pad;
+            A.bias_first = Ly.bA_first.as<float>(); A.bias_rest = Ly.bA_rest.as<float>();
+            A.E0 = H; A.O0 = P1; A.O1 = P2; A.epi = REC_GRU_A;                    // Z, r.h
+            RecStreamSeg srh{};
+            srh.A = P2; srh.ld = U_pad; srh.nb = nbu; srh.prev = 0; srh.skip_first = 1; srh.dep = rA; srh.dep_mult = (unsigned)ncA;
+            B.seg[1] = srh; B.W = Ly.WB.as<float>(); B.ldw = Ly.Kx + U_pad;
+            B.bias_first = Ly.bB_first.as<float>(); B.bias_rest = Ly.bB_rest.as<float>();
+            B.E0 = H; B.E1 = P1; B.O0 = H; B.epi = REC_GRU_B; B.edep = rA; B.edep_mult = (unsigned)ncA;
+        } else {   // AM_CELL_PEEPHOLE
+            RecStreamSeg sc{};   // the cell state of the previous step
+            sc.A = P1; sc.ld = U_pad; sc.nb = nbu; sc.prev = 1; sc.skip_first = 1; sc.dep = rA; sc.dep_mult = (unsigned)ncA;
+            A.seg[1] = sh; A.seg[2] = sc; A.W = Ly.WA.as<float>(); A.ldw = Ly.Kx + 2 * U_pad;
+            A.bias_first = Ly.bA_first.as<float>(); A.bias_rest = Ly.bA_first.as<float>();
+            A.E0 = P1; A.O0 = P1; A.O1 = P2; A.epi = REC_PEEP_A;                   // c', the o pre-activation
+            RecStreamSeg scn{};  // c' of this step
+            scn.A = P1; scn.ld = U_pad; scn.nb = nbu; scn.prev = 0; scn.skip_first = 0; scn.dep = rA; scn.dep_mult = (unsigned)ncA;
+            B.seg[0] = scn; B.W = Ly.WB.as<float>(); B.ldw = U_pad;
+            B.bias_first = Ly.bB_first.as<float>(); B.bias_rest = Ly.bB_first.as<float>();
+            B.E0 = P1; B.E1 = P2; B.O0 = H; B.epi = REC_PEEP_B;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(pl.d_roles.p, roles.data(), sizeof(RecStreamRole) * roles.size(), hipMemcpyHostToDevice, e->stream));   // (pageable source: staged before the call returns)
+    ra.roles = pl.d_roles.as<RecStreamRole>();
+    ra.n_active = p->d_nact.as<int>(); ra.step_off = p->d_stepoff.as<int>();
+    ra.counters = p->d_sync.as<unsigned>(); ra.abort_flag = p->d_sync.as<int>() + 63;
+    HIP_TRY(hipMemsetAsync(p->d_sync.p, 0, sizeof(unsigned) * 63, e->stream));
+    PersistGate& G = gate_of(e);   // one persistent launch at a time per device: every workgroup must be resident
+    std::lock_guard<std::mutex> lk(G.mu);
+    if (G.last && G.owner != e) HIP_TRY(hipStreamWaitEvent(e->stream, G.last, 0));
+    AM_TRY(run_kernel(e, K_LSTM_STEP, [&] { return launch_rec_stream(e->stream, ra); }));
+    HIP_TRY(hipEventRecord(e->persist_done, e->stream));
+    G.last = e->persist_done; G.owner = e;
+    p->used_persist = true;
+    return AM_OK;
+}
+
 static int lstm_enqueue(am_pipeline* p)
 {
     am_engine* e = p->e;
@@ -1841,7 +1951,8 @@ static int lstm_enqueue(am_pipeline* p)
         const int U_pad = m->L[0].U_pad;
         const size_t h_stride = (size_t)(rows_pad + GEMM_BM) * U_pad;   // per-layer H plane
         const size_t c_stride = (size_t)round_up(std::max(p->n_slots, 1), 16) * U_pad;
-        if (m->cell != AM_CELL_LSTM) AM_TRY(rec_stack(p, m, h_stride));
+        if (m->cell != AM_CELL_LSTM && p->persist[mi].form == 3) AM_TRY(rec_stack_stream(p, mi, h_stride));
+        else if (m->cell != AM_CELL_LSTM) AM_TRY(rec_stack(p, m, h_stride));
         else {
         // layer 0: its input is known up front -> hoist the upward projection of ALL frames into one bulk GEMM
         {

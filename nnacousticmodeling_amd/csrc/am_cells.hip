@@ -17,28 +17,10 @@ namespace am {
 template <int G, int EPI>
 __device__ __forceinline__ void rec_epilogue(const float (&pre)[G], float e0, float e1, int first, int act, const RecLayerStep& Ls, size_t eidx)
 {
-    if (EPI == REC_MGRU || EPI == REC_GRU_B) {
-        // linear_interpolate(z, h~, h) = z*h~ + (1-z)*h ; without a previous state h = z*h~ (MGRU.py:77-84)
-        const float z = EPI == REC_MGRU ? am_sigmoid_rec(pre[0]) : e1;
-        const float hb = am_activate_rec(pre[G - 1], act);
-        float h = z * hb;
-        if (!first) { const float keep = (1.0f - z) * e0; h = h + keep; }
-        Ls.O0[eidx] = h;
-    } else if (EPI == REC_GRU_A) {
-        Ls.O0[eidx] = am_sigmoid_rec(pre[G - 1]);                                   // z
-        Ls.O1[eidx] = first ? 0.0f : am_sigmoid_rec(pre[0]) * e0;                   // r * h_prev
-    } else if (EPI == REC_PEEP_A) {
-        const float a = am_tanh_rec(pre[0]);
-        const float i = am_sigmoid_rec(pre[1 % G]);
-        const float f = am_sigmoid_rec(pre[2 % G]);
-        const float ai = a * i;
-        const float fc = f * e0;
-        Ls.O0[eidx] = ai + fc;                                                  // c'
-        Ls.O1[eidx] = pre[3 % G];                                               // o before its peephole term
-    } else {                                                                    // REC_PEEP_B
-        const float o = am_sigmoid_rec(e1 + pre[0]);
-        Ls.O0[eidx] = o * am_tanh_rec(e0);
-    }
+    float o0, o1 = 0.0f;
+    rec_cell_math<G, EPI>(pre, e0, e1, first, act, o0, o1);   // (am_device.h: shared with the persistent form)
+    Ls.O0[eidx] = o0;
+    if (EPI == REC_GRU_A || EPI == REC_PEEP_A) Ls.O1[eidx] = o1;
 }
 
 template <int G, int EPI, int R>
@@ -378,9 +360,12 @@ static hipError_t rec_init()
     return hipFuncSetAttribute((const void*)rec_step_kernel<G, EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)REC_LDS_MAX);
 }
 
+hipError_t init_rec_stream_kernel();   // am_cells_stream.hip
+
 hipError_t init_rec_kernels()
 {
     hipError_t e;
+    if ((e = init_rec_stream_kernel()) != hipSuccess) return e;
     if ((e = rec_init<2, REC_MGRU>()) != hipSuccess) return e;
     if ((e = rec_init<2, REC_GRU_A>()) != hipSuccess) return e;
     if ((e = rec_init<1, REC_GRU_B>()) != hipSuccess) return e;

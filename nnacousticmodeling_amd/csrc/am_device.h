@@ -76,12 +76,44 @@ __device__ __forceinline__ void st_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned b
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, 0, 16 /* sc1 */);
 }
 
+// The element-wise arithmetic of the cells other than L.LSTM, one phase (RecEpilogue) of one unit: shared by the per-tick kernels (am_cells.hip) and the
+// persistent form (am_cells_stream.hip), so that a frame's posteriors do not depend on the form that computed them.
+//   MGRU / GRU_B: linear_interpolate(z, h~, h) = z h~ + (1 - z) h; without a previous state h = z h~ (MGRU.py:77-84).  e0 = h_prev, e1 = Z (GRU_B)
+//   GRU_A       : o0 = Z = sig(z), o1 = sig(r) h_prev                                                                   e0 = h_prev
+//   PEEP_A      : o0 = c' = tanh(a) sig(i) + sig(f) c, o1 = o before its peephole term                                  e0 = c_prev
+//   PEEP_B      : o0 = h = sig(O + peep_o c') tanh(c')                                                                  e0 = c', e1 = O
+template <int G, int EPI>
+__device__ __forceinline__ void rec_cell_math(const float (&pre)[G], float e0, float e1, int first, int act, float& o0, float& o1)
+{
+    if (EPI == REC_MGRU || EPI == REC_GRU_B) {
+        const float z = EPI == REC_MGRU ? am_sigmoid_rec(pre[0]) : e1;
+        const float hb = am_activate_rec(pre[G - 1], act);
+        float h = z * hb;
+        if (!first) { const float keep = (1.0f - z) * e0; h = h + keep; }
+        o0 = h;
+    } else if (EPI == REC_GRU_A) {
+        o0 = am_sigmoid_rec(pre[G - 1]);
+        o1 = first ? 0.0f : am_sigmoid_rec(pre[0]) * e0;
+    } else if (EPI == REC_PEEP_A) {
+        const float a = am_tanh_rec(pre[0]);
+        const float i = am_sigmoid_rec(pre[1 % G]);
+        const float f = am_sigmoid_rec(pre[2 % G]);
+        const float ai = a * i;
+        const float fc = f * e0;
+        o0 = ai + fc;
+        o1 = pre[3 % G];
+    } else {
+        const float o = am_sigmoid_rec(e1 + pre[0]);
+        o0 = o * am_tanh_rec(e0);
+    }
+}
+
 // geometry shared by the GEMM kernels (am_gemm.hip, am_gemm_split.hip): 512-thread blocks, 8 waves as 4 (M) x 2 (N)
 constexpr int GEMM_WM = 4, GEMM_WN = 2, GEMM_THREADS = 64 * GEMM_WM * GEMM_WN;
 
 // geometry shared by the recurrent kernels (am_lstm_step.hip, am_lstm_persist.hip, am_cells.hip)
 constexpr int LSTM_RB = 64;               // rows per block
-constexpr int LSTM_KB = 128;              // k per batch (both K halves)
+// (LSTM_KB = 128, k per batch (both K halves): am_internal.h -- the host plans in batches too)
 constexpr int LSTM_KS = LSTM_KB / 32;     // 16-k sub-steps per wave per batch
 constexpr int LSTM_LDA = LSTM_KB + 8;     // LDS row stride (floats): +32 B -> ds_read_b128 of (row l15, chunk lq) is conflict-free in every 16-lane service
                                           // group (+16 B left a 2-way conflict per group: SQ_LDS_BANK_CONFLICT, profiles/r2b)

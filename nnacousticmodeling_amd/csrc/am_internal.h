@@ -127,6 +127,7 @@ struct GatherArgs {
 hipError_t launch_gather_ft(hipStream_t s, const GatherArgs& a);
 
 constexpr int LSTM_MAX_LAYERS = 8;
+constexpr int LSTM_KB = 128;   // k per batch of the recurrent kernels (both K halves): recurrent widths and inputs are padded to multiples of it
 struct LstmLayerStep {   // one layer's time step inside a wavefront launch
     const float* G;      // [>= rows, 4*U_pad] hoisted upward pre-activations (+bias) of this step's rows, or nullptr
     const float* bias;   // [4*U_pad] gate-tiled, used when G == nullptr
@@ -220,6 +221,34 @@ struct RecStepArgs {
     int bt_groups;                 // set by the launcher of rec_wide_kernel
 };
 hipError_t launch_rec_step(hipStream_t s, int epilogue, const RecStepArgs& a);
+
+// The same cells as ONE persistent launch (rec_stream_kernel, am_cells_stream.hip): a role = one phase of one layer.
+constexpr int RS_MAX_ROLES = 16;
+struct RecStreamSeg {
+    const float* A; int ld;      // time-major plane [rows, ld] the segment's rows come from
+    int nb;                      // 128-k batches (0: no such segment)
+    int prev;                    // 1: rows of step t - 1; 0: rows of step t
+    int skip_first;              // 1: the segment does not exist at t == 0 (the state Linears of a cell without a previous state)
+    int dep; unsigned dep_mult;  // the role (counter index) that produces those rows in this launch, and its arrivals per step; -1: the plane was complete before the launch
+};
+struct RecStreamRole {
+    RecStreamSeg seg[3];
+    const float* W; int ldw;                       // packed weights [G U_pad, ldw]
+    const float* bias_first; const float* bias_rest;
+    const float* E0; const float* E1;              // element-wise inputs, time-major planes [rows, U_pad] (rec_cell_math); E0 of MGRU / GRU / PEEP_A: rows of step t - 1
+    float* O0; float* O1;                          // element-wise outputs
+    int edep; unsigned edep_mult;                  // role whose step-t output the epilogue reads when no tile wait covers it (GRU B at t == 0: Z); -1: none
+    int epi, n_col, wg0, counter;                  // RecEpilogue; 64-column workgroups of the role; first workgroup (within a group); counter index
+};
+struct RecStreamArgs {
+    const RecStreamRole* roles;                    // device [n_roles]
+    int n_roles, NG, wgs_per_group, T, U_pad, U_real, act, max_wgs;
+    const int* n_active; const int* step_off;      // device [T], [T + 1]
+    unsigned* counters;                            // device [n_roles][NG], zero before the launch
+    int* abort_flag;
+};
+int rec_stream_resident_wgs(int n_cus);
+hipError_t launch_rec_stream(hipStream_t s, const RecStreamArgs& a);
 
 struct ViterbiArgs {
     int P, B, T;                       // phones (start/end nodes), biphone nodes, triphones

@@ -103,3 +103,33 @@ def test_cell_argument_errors(engine):
         Model(engine, "gru", 1, bad)
     with pytest.raises(KeyError):
         Model(engine, "gru", 1, orc.make_gru_params(rng, 40, 32, 1, 10, reset_gate=False))
+
+
+@pytest.mark.parametrize("network,layers,units,n_utts", [("gru", 3, 512, 192), ("mgrurelu", 3, 512, 192), ("mgrurelur", 2, 512, 100), ("peepholelstm", 3, 512, 150),
+                                                         ("gru", 2, 72, 40), ("mgrurelu", 1, 256, 70), ("peepholelstm", 2, 100, 33), ("gru", 4, 256, 192)])
+def test_persistent_cell_form_equals_the_per_tick_kernels(engine, real_ft_path, monkeypatch, network, layers, units, n_utts):
+    """Round 4: GRU / MGRU / peephole stacks as ONE persistent launch (rec_stream_kernel: roles = phases of layers, row groups by tile round-robin,
+    weights streamed) against the per-tick phase kernels (AM_REC_STREAM=0): same summation order and cell arithmetic, so the same bits -- whole file,
+    with a time delay, thin tails (utterances of 3..140 frames), widths with pad units; plus the oracle on a sample."""
+    ft = orc.centre_frame_transform(orc.load_kaldi_feature_transform(real_ft_path))
+    rng = np.random.default_rng(31 * layers + units + n_utts)
+    params = _params(network, rng, 40, units, layers, 1909)
+    n = 45 * n_utts
+    off = orc.make_offsets(rng, n_utts, n, lo=3, hi=140)
+    x = rng.standard_normal((n, 40)).astype(np.float32)
+    p = _pipe(engine, network, layers, params, ft)
+    monkeypatch.setenv("AM_REC_STREAM", "2")          # (read once per process by the library: see below)
+    whole = p.forward_lstm(x, off, timedelay=2)
+    form = p.recurrent_form()
+    p.lstm_run()
+    assert np.array_equal(p.lstm_download(), whole)   # idempotent: counters re-armed per launch, planes written once per launch
+    monkeypatch.setenv("AM_LSTM_PERSIST", "0")        # every persistent form off (read at upload): the per-tick kernels
+    ticks = p.forward_lstm(x, off, timedelay=2)
+    monkeypatch.delenv("AM_LSTM_PERSIST")
+    assert p.recurrent_form() == (0, 1)
+    assert form == (1, 1), form
+    assert np.array_equal(ticks, whole)
+    k = min(n_utts, 5)
+    want = orc.predict(orc.get_nn(network, layers, params), x[:off[k]], off[:k + 1], True, 1, 2, ft)
+    assert np.max(np.abs(whole[:off[k]] - want)) <= TOL
+    p.close()
