@@ -107,6 +107,7 @@ struct Layer {
     DevBuf Whi, Wlo, b_s;
     // other recurrent cells (am_model_create_rnn): packed phase weights and their bias vectors, see RecEpilogue
     DevBuf WA, WB, bA_first, bA_rest, bB_first, bB_rest;
+    DevBuf WAs, WBs;       // WA, WB in the order the persistent cell kernel streams them (rec_stream_pack_weights)
     int Kx = 0;            // padded input width of the cell (multiple of 64)
 };
 
@@ -176,10 +177,14 @@ struct am_pipeline {
         RecStreamArgs rsa{};                   // form 3: the cells' persistent launch (rec_stream_kernel) and its role table on the device
         DevBuf d_roles;
         std::vector<RecStreamRole> h_roles;    // (the host copy the asynchronous upload reads from: lives as long as the plan)
-        void release() { for (auto& c : cums) c.release(); cums.clear(); chunks.clear(); layer0.clear(); d_roles.release(); form = 0; }
+        bool split = false;                    // form 3: the upper layers' phases run as two roles each (input part / state part)
+        DevBuf d_xplanes;                      // ... and these are the accumulator planes between them
+        void release() { for (auto& c : cums) c.release(); cums.clear(); chunks.clear(); layer0.clear(); d_roles.release(); d_xplanes.release(); form = 0; split = false; }
     };
     std::vector<PersistPlan> persist;
     DevBuf d_nact, d_stepoff, d_sync;   // int [T], int [T + 1], unsigned [groups + 1] (arrival counters, abort flag last)
+    DevBuf d_tileoff;                   // int [T]: 16-row tiles of the steps before t (rec_stream_kernel's split phases)
+    int64_t total_tiles = 0;
     DevBuf d_stamps;                    // AM_LSTM_STAMPS=1: timeline of the last member's persistent launch (am_lstm_stamps)
     int stamps_groups = 0, stamps_T = 0;
     bool used_persist = false;
@@ -526,6 +531,14 @@ static int upload(am_engine* e, DevBuf& d, const std::vector<float>& h)
     return AM_OK;
 }
 
+// a second copy of a cell's packed weights [rows, ld], in the order the persistent cell kernel streams them
+static int upload_stream_order(am_engine* e, DevBuf& d, const std::vector<float>& w, int rows, int ld)
+{
+    std::vector<float> s(w.size());
+    rec_stream_pack_weights(w.data(), rows, ld, s.data());
+    return upload(e, d, s);
+}
+
 // destination row of (unit u, gate k) in the gate-tiled layout used by lstm_wavefront_kernel
 static inline int gate_tiled_row(int u, int k) { return (u / 16) * 64 + k * 16 + (u % 16); }
 
@@ -606,7 +619,7 @@ extern "C" int am_model_destroy(am_model* m)
     (void)hipSetDevice(m->e->device);
     for (auto& l : m->L) {
         l.W.release(); l.b.release(); l.Wlat.release(); l.Whi.release(); l.Wlo.release(); l.b_s.release();
-        l.WA.release(); l.WB.release(); l.bA_first.release(); l.bA_rest.release(); l.bB_first.release(); l.bB_rest.release();
+        l.WA.release(); l.WB.release(); l.WAs.release(); l.WBs.release(); l.bA_first.release(); l.bA_rest.release(); l.bB_first.release(); l.bB_rest.release();
     }
     am_engine* e = m->e;
     delete m;
@@ -732,6 +745,7 @@ extern "C" int am_model_create_rnn(am_engine* e, int cell, int n_layers, int act
                 }
                 if ((rc = upload(e, Ly.WA, wa)) != AM_OK || (rc = upload(e, Ly.bA_first, af)) != AM_OK || (rc = upload(e, Ly.bA_rest, ar)) != AM_OK) break;
                 if ((rc = upload(e, Ly.WB, wb)) != AM_OK || (rc = upload(e, Ly.bB_first, bf)) != AM_OK || (rc = upload(e, Ly.bB_rest, br)) != AM_OK) break;
+                if ((rc = upload_stream_order(e, Ly.WAs, wa, 2 * U_pad, ld)) != AM_OK || (rc = upload_stream_order(e, Ly.WBs, wb, U_pad, ld)) != AM_OK) break;
             } else {
                 std::vector<float> wa((size_t)2 * U_pad * ld, 0.f), af(2 * U_pad, 0.f), ar(2 * U_pad, 0.f);
                 for (int u = 0; u < U; ++u) {
@@ -739,6 +753,7 @@ extern "C" int am_model_create_rnn(am_engine* e, int cell, int n_layers, int act
                     fill(wa, af, ar, row_of(u, 1, 2), u, P[o + 4], P[o + 5], P[o + 6], P[o + 7]);   // candidate
                 }
                 if ((rc = upload(e, Ly.WA, wa)) != AM_OK || (rc = upload(e, Ly.bA_first, af)) != AM_OK || (rc = upload(e, Ly.bA_rest, ar)) != AM_OK) break;
+                if ((rc = upload_stream_order(e, Ly.WAs, wa, 2 * U_pad, ld)) != AM_OK) break;
             }
         } else {   // AM_CELL_PEEPHOLE: upward.W [4U,in], upward.b [4U], lateral.W [4U,U] (gates interleaved 4u+g), peep_i/f/o.W [U,U]
             const int ld = Kx + 2 * U_pad;
@@ -756,6 +771,7 @@ extern "C" int am_model_create_rnn(am_engine* e, int cell, int n_layers, int act
             }
             if ((rc = upload(e, Ly.WA, wa)) != AM_OK || (rc = upload(e, Ly.bA_first, ab)) != AM_OK) break;
             if ((rc = upload(e, Ly.WB, wb)) != AM_OK || (rc = upload(e, Ly.bB_first, zb)) != AM_OK) break;
+            if ((rc = upload_stream_order(e, Ly.WAs, wa, 4 * U_pad, ld)) != AM_OK || (rc = upload_stream_order(e, Ly.WBs, wb, U_pad, U_pad)) != AM_OK) break;
         }
         m->max_width = std::max(m->max_width, U_pad);
     }
@@ -797,7 +813,7 @@ extern "C" int am_pipeline_destroy(am_pipeline* p)
     for (auto ev : p->ev_chain) if (ev) (void)hipEventDestroy(ev);
     p->drop_graph();
     for (DevBuf* d : {&p->d_shifts, &p->d_add, &p->d_scale, &p->d_rplw, &p->d_rplb, &p->d_rpllb, &p->d_prior, &p->d_x, &p->d_ivec, &p->d_in, &p->d_in_s,
-                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_stack, &p->d_ffsync, &p->d_stack2, &p->d_ffsync2, &p->d_accs, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c, &p->d_cplane, &p->d_recplanes, &p->d_nact, &p->d_stepoff, &p->d_sync, &p->d_stamps})
+                      &p->d_act0, &p->d_act1, &p->d_acc, &p->d_acc2, &p->d_out, &p->d_stack, &p->d_ffsync, &p->d_stack2, &p->d_ffsync2, &p->d_accs, &p->d_src, &p->d_dst, &p->d_G, &p->d_H, &p->d_c, &p->d_cplane, &p->d_recplanes, &p->d_nact, &p->d_stepoff, &p->d_tileoff, &p->d_sync, &p->d_stamps})
         d->release();
     for (auto& pl : p->persist) pl.release();
     am_engine* e = p->e;
@@ -1576,29 +1592,64 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
         HIP_TRY(hipMemcpyAsync(p->d_nact.p, nact.data(), sizeof(int) * nact.size(), hipMemcpyHostToDevice, e->stream));
         HIP_TRY(hipMemcpyAsync(p->d_stepoff.p, soff.data(), sizeof(int) * soff.size(), hipMemcpyHostToDevice, e->stream));
         AM_TRY(p->d_sync.ensure(sizeof(unsigned) * 64));
+        std::vector<int> toff(nact.size());
+        p->total_tiles = 0;
+        for (size_t t = 0; t < nact.size(); ++t) { toff[t] = (int)p->total_tiles; p->total_tiles += (nact[t] + 15) / 16; }
+        AM_TRY(p->d_tileoff.ensure(sizeof(int) * std::max<size_t>(toff.size(), 1)));
+        HIP_TRY(hipMemcpyAsync(p->d_tileoff.p, toff.data(), sizeof(int) * toff.size(), hipMemcpyHostToDevice, e->stream));   // (synchronised below, with the tables above)
         std::vector<std::vector<unsigned>> staging;   // alive until the copies below have been synchronised
         for (size_t mi = 0; mi < p->members.size(); ++mi) {
             am_model* m = p->members[mi];
             if (m->cell != AM_CELL_LSTM) {
-                // GRU / MGRU / peephole stacks: the persistent form (rec_stream_kernel) when its row groups fill the chip -- at least two groups, or a
-                // file of at most four row tiles; otherwise (1024-unit stacks: one group of 192 workgroups would take every row in three passes) the
-                // per-tick phase kernels.  AM_REC_STREAM=0 never, 2 whenever it fits.
-                static const int64_t rs_mode = env_int("AM_REC_STREAM", 1);
+                // GRU / MGRU / peephole stacks: the per-tick phase kernels, unless AM_REC_STREAM asks for the persistent form (rec_stream_kernel): measured
+                // on the 3 x 512 recipes it is 5-15 % SLOWER than they are (GRU 22.5 against 19.8 ms, MGRU 11.7 / 11.2, peephole 32.9 / 28.6),
+                // so it is there to be measured, not used.  1 = when its row groups fill the chip -- at least two groups, or a file of at most four row
+                // tiles (1024-unit stacks: one group of 192 workgroups would take every row in three passes) --, 2 = whenever it fits.
+                const int64_t rs_mode = env_int("AM_REC_STREAM", 0);   // (read at every upload, like AM_LSTM_PERSIST)
+                // A phase of an upper layer can run as TWO roles: the input part (h of the layer below times W_x -- no dependency on the recurrence, it runs
+                // ahead) and the state part, which starts its accumulators from what the input part left: the chain a step has to wait for is half as
+                // long, at the price of more workgroups per row group, i.e. more row tiles per workgroup.  Taken when batches x tiles of the longest
+                // chain come out smaller (3 x 512 MGRU, 192 utterances: 8 batches x 3 tiles -> 5 x 4; GRU: 16 x 4 -> 10 x 6).  AM_REC_SPLIT=0 never,
+                // 2 whenever it fits.
+                const int64_t split_mode = env_int("AM_REC_SPLIT", 0);   // (read at every upload: the tests compare both forms in one process)
                 const int n_phase = m->cell == AM_CELL_MGRU ? 1 : 2;
                 const int U_pad = m->L[0].U_pad, NL = m->n_layers;
                 const int ncA = (m->cell == AM_CELL_PEEPHOLE ? 4 : 2) * U_pad / 64, ncB = U_pad / 64;
-                const int per_group = NL * (ncA + (n_phase == 2 ? ncB : 0));
                 const int swgs = rs_mode ? rec_stream_resident_wgs(e->n_cus) : 0;
                 const int tiles = (n_utts + 15) / 16;
-                int NG = per_group > 0 ? swgs / per_group : 0;
-                NG = std::min(NG, std::max(tiles, 1));
-                while (NG > 0 && NL * n_phase * NG > 62) --NG;   // arrival counters: d_sync holds 63
-                if (NG < 1 || NL * n_phase > RS_MAX_ROLES || (rs_mode != 2 && NG < 2 && tiles > 4)) continue;
+                struct Opt { int per_group = 0, n_roles = 0, NG = 0; long cost = 0; };
+                auto option = [&](bool split) {
+                    Opt o;
+                    const int per_layer = ncA + (n_phase == 2 ? ncB : 0);
+                    o.per_group = split ? per_layer * (1 + 2 * (NL - 1)) : NL * per_layer;
+                    o.n_roles = split ? n_phase * (1 + 2 * (NL - 1)) : NL * n_phase;
+                    o.NG = o.per_group > 0 ? swgs / o.per_group : 0;
+                    o.NG = std::min(o.NG, std::max(tiles, 1));
+                    while (o.NG > 0 && o.n_roles * o.NG > 62) --o.NG;   // arrival counters: d_sync holds 63
+                    if (o.n_roles > RS_MAX_ROLES) o.NG = 0;
+                    if (o.NG < 1) return o;
+                    const int nbx0 = m->L[0].Kx / LSTM_KB, nbu = U_pad / LSTM_KB;
+                    const int state = m->cell == AM_CELL_PEEPHOLE ? 3 * nbu : n_phase * nbu;       // k-batches of a step's chain without / with the input part
+                    const int chain0 = state + n_phase * nbx0, chain = NL > 1 ? (split ? state : state + (m->cell == AM_CELL_PEEPHOLE ? 1 : n_phase) * nbu) : 0;
+                    o.cost = (long)std::max(chain0, chain) * ((tiles + o.NG - 1) / o.NG);
+                    return o;
+                };
+                Opt o = option(false);
+                bool split = false;
+                if (split_mode && NL > 1 && m->cell != AM_CELL_PEEPHOLE) {
+                    const Opt os = option(true);
+                    if (os.NG >= 1 && (o.NG < 1 || split_mode == 2 || os.cost < o.cost)) { o = os; split = true; }
+                }
+                const int NG = o.NG;
+                if (NG < 1 || (rs_mode != 2 && NG < 2 && tiles > 4)) continue;
                 auto& pl = p->persist[mi];
                 RecStreamArgs& ra = pl.rsa;
                 ra = RecStreamArgs{};
-                ra.n_roles = NL * n_phase; ra.NG = NG; ra.wgs_per_group = per_group; ra.T = (int)T; ra.U_pad = U_pad; ra.U_real = m->L[0].U; ra.act = m->act; ra.max_wgs = swgs;
+                ra.n_roles = o.n_roles; ra.NG = NG; ra.wgs_per_group = o.per_group; ra.T = (int)T; ra.U_pad = U_pad; ra.U_real = m->L[0].U; ra.act = m->act; ra.max_wgs = swgs;
                 AM_TRY(pl.d_roles.ensure(sizeof(RecStreamRole) * RS_MAX_ROLES));
+                pl.split = split;
+                if (split)   // per upper layer: [total tiles][64-column workgroups of its phases][8 KB]
+                    AM_TRY(pl.d_xplanes.ensure(sizeof(float) * 2048 * (size_t)p->total_tiles * (size_t)(ncA + (n_phase == 2 ? ncB : 0)) * (size_t)(NL - 1)));
                 pl.form = 3; any_persist = true; any_recstream = true;
                 continue;
             }
@@ -1853,62 +1904,100 @@ static int rec_stack_stream(am_pipeline* p, int mi, size_t h_stride)
     float* X = p->d_recplanes.as<float>();
     std::vector<RecStreamRole>& roles = pl.h_roles;
     roles.assign(ra.n_roles, RecStreamRole{});
+    // Role numbering.  Whole phases: layer l -> n_phase l (+ 1 for phase B).  Split (pl.split; upper layers only): layer 0 as before, layer l >= 1 ->
+    // n_phase + 2 n_phase (l - 1) + {input part of A, [input part of B,] state part of A [, state part of B]}.
+    const bool split = pl.split;
+    auto role_of = [&](int l, int phase, bool input_part) {
+        if (!split || l == 0) return n_phase * l + phase;
+        return n_phase + 2 * n_phase * (l - 1) + (input_part ? 0 : n_phase) + phase;
+    };
+    const size_t xplane_cols = (size_t)(ncA + (n_phase == 2 ? ncB : 0));   // 64-column workgroups of a layer's phases: the layer's share of d_xplanes
+    RecStreamSeg none{}; none.dep = -1;
     int wg = 0;
+    auto place = [&](RecStreamRole& R, int idx, int n_col) { R.n_col = n_col; R.wg0 = wg; R.counter = idx; wg += n_col; };
     for (int l = 0; l < NL; ++l) {
         Layer& Ly = m->L[l];
         float* H = Hall + l * h_stride;
         float* P1 = X + (size_t)(2 * l) * h_stride; float* P2 = X + (size_t)(2 * l + 1) * h_stride;
-        const int rA = n_phase * l, rB = n_phase * l + 1;
-        const int below = l > 0 ? n_phase * (l - 1) + (n_phase - 1) : -1;       // the role that writes h of the layer below
-        const unsigned below_mult = (unsigned)(n_phase == 1 ? ncA : ncB);
+        const bool sp = split && l > 0;
+        const int rA = role_of(l, 0, false), rB = role_of(l, 1, false);
+        const int hw = n_phase == 1 ? rA : rB;                                    // the role that writes this layer's h
+        const int below = l > 0 ? role_of(l - 1, n_phase - 1, false) : -1;        // ... and the layer below's
+        const unsigned below_mult = (unsigned)(n_phase == 1 ? ncA : ncB), hw_mult = below_mult;
+        const int nbx = Ly.Kx / LSTM_KB;
+        float* xp = sp ? pl.d_xplanes.as<float>() + (size_t)2048 * p->total_tiles * xplane_cols * (size_t)(l - 1) : nullptr;   // this layer's accumulator planes: A, then B
         RecStreamSeg sx{};   // the cell's input: the gathered frames (layer 0) or h of the layer below at the same step
-        sx.A = l == 0 ? p->d_in.as<float>() : Hall + (l - 1) * h_stride; sx.ld = l == 0 ? m->in_pad : U_pad; sx.nb = Ly.Kx / LSTM_KB;
-        sx.prev = 0; sx.skip_first = 0; sx.dep = below; sx.dep_mult = below_mult;
-        RecStreamSeg none{}; none.dep = -1;
+        sx.A = l == 0 ? p->d_in.as<float>() : Hall + (l - 1) * h_stride; sx.ld = l == 0 ? m->in_pad : U_pad; sx.nb = nbx;
+        sx.prev = 0; sx.skip_first = 0; sx.dep = below; sx.dep_mult = below_mult; sx.wb0 = 0;
+        RecStreamSeg sh{};   // h of this layer at the previous step
+        sh.A = H; sh.ld = U_pad; sh.nb = nbu; sh.prev = 1; sh.skip_first = 1; sh.dep = hw; sh.dep_mult = hw_mult; sh.wb0 = nbx;
+        // the input part of phase `ph` as a role of its own
+        auto input_role = [&](int ph, const float* W, int ldw, int n_col, float* plane) {
+            const int idx = role_of(l, ph, true);
+            RecStreamRole& R = roles[idx];
+            R = RecStreamRole{};
+            R.seg[0] = sx; R.seg[1] = none; R.seg[2] = none;
+            R.W = W; R.ldw = ldw; R.epi = REC_XPART; R.edep = -1; R.idep = -1; R.xplane = plane;
+            place(R, idx, n_col);
+        };
+        if (sp) {
+            input_role(0, Ly.WAs.as<float>(), Ly.Kx + U_pad, ncA, xp);
+            if (n_phase == 2) input_role(1, Ly.WBs.as<float>(), Ly.Kx + U_pad, ncB, xp + (size_t)2048 * p->total_tiles * ncA);
+        }
         RecStreamRole& A = roles[rA];
         A = RecStreamRole{};
-        A.seg[0] = sx; A.seg[1] = none; A.seg[2] = none;
-        A.n_col = ncA; A.wg0 = wg; A.counter = rA; A.edep = -1; wg += ncA;
-        const int hw = n_phase == 1 ? rA : rB;                                   // the role that writes this layer's h
-        RecStreamSeg sh{};   // h of this layer at the previous step
-        sh.A = H; sh.ld = U_pad; sh.nb = nbu; sh.prev = 1; sh.skip_first = 1; sh.dep = hw; sh.dep_mult = (unsigned)(n_phase == 1 ? ncA : ncB);
+        A.seg[0] = sp ? none : sx; A.seg[1] = none; A.seg[2] = none;
+        A.edep = -1; A.idep = -1;
+        if (sp) { A.init = xp; A.idep = role_of(l, 0, true); A.idep_mult = (unsigned)ncA; }
+        place(A, rA, ncA);
         if (m->cell == AM_CELL_MGRU) {
-            A.seg[1] = sh; A.W = Ly.WA.as<float>(); A.ldw = Ly.Kx + U_pad;
+            A.seg[1] = sh; A.W = Ly.WAs.as<float>(); A.ldw = Ly.Kx + U_pad;
             A.bias_first = Ly.bA_first.as<float>(); A.bias_rest = Ly.bA_rest.as<float>();
             A.E0 = H; A.O0 = H; A.epi = REC_MGRU;
             continue;
         }
         RecStreamRole& B = roles[rB];
         B = RecStreamRole{};
-        B.seg[0] = sx; B.seg[1] = none; B.seg[2] = none;
-        B.n_col = ncB; B.wg0 = wg; B.counter = rB; B.edep = -1; wg += ncB;
+        B.seg[0] = sp ? none : sx; B.seg[1] = none; B.seg[2] = none;
+        B.edep = -1; B.idep = -1;
+        if (sp) { B.init = xp + (size_t)2048 * p->total_tiles * ncA; B.idep = role_of(l, 1, true); B.idep_mult = (unsigned)ncB; }
+        place(B, rB, ncB);
         if (m->cell == AM_CELL_GRU) {
-            A.seg[1] = sh; A.W = Ly.WA.as<float>(); A.ldw = Ly.Kx + U_pad;
+            A.seg[1] = sh; A.W = Ly.WAs.as<float>(); A.ldw = Ly.Kx + U_pad;
             A.bias_first = Ly.bA_first.as<float>(); A.bias_rest = Ly.bA_rest.as<float>();
             A.E0 = H; A.O0 = P1; A.O1 = P2; A.epi = REC_GRU_A;                    // Z, r.h
             RecStreamSeg srh{};
-            srh.A = P2; srh.ld = U_pad; srh.nb = nbu; srh.prev = 0; srh.skip_first = 1; srh.dep = rA; srh.dep_mult = (unsigned)ncA;
-            B.seg[1] = srh; B.W = Ly.WB.as<float>(); B.ldw = Ly.Kx + U_pad;
+            srh.A = P2; srh.ld = U_pad; srh.nb = nbu; srh.prev = 0; srh.skip_first = 1; srh.dep = rA; srh.dep_mult = (unsigned)ncA; srh.wb0 = nbx;
+            B.seg[1] = srh; B.W = Ly.WBs.as<float>(); B.ldw = Ly.Kx + U_pad;
             B.bias_first = Ly.bB_first.as<float>(); B.bias_rest = Ly.bB_rest.as<float>();
             B.E0 = H; B.E1 = P1; B.O0 = H; B.epi = REC_GRU_B; B.edep = rA; B.edep_mult = (unsigned)ncA;
-        } else {   // AM_CELL_PEEPHOLE
+        } else {   // AM_CELL_PEEPHOLE (never split)
             RecStreamSeg sc{};   // the cell state of the previous step
-            sc.A = P1; sc.ld = U_pad; sc.nb = nbu; sc.prev = 1; sc.skip_first = 1; sc.dep = rA; sc.dep_mult = (unsigned)ncA;
-            A.seg[1] = sh; A.seg[2] = sc; A.W = Ly.WA.as<float>(); A.ldw = Ly.Kx + 2 * U_pad;
+            sc.A = P1; sc.ld = U_pad; sc.nb = nbu; sc.prev = 1; sc.skip_first = 1; sc.dep = rA; sc.dep_mult = (unsigned)ncA; sc.wb0 = nbx + nbu;
+            A.seg[1] = sh; A.seg[2] = sc; A.W = Ly.WAs.as<float>(); A.ldw = Ly.Kx + 2 * U_pad;
             A.bias_first = Ly.bA_first.as<float>(); A.bias_rest = Ly.bA_first.as<float>();
             A.E0 = P1; A.O0 = P1; A.O1 = P2; A.epi = REC_PEEP_A;                   // c', the o pre-activation
             RecStreamSeg scn{};  // c' of this step
-            scn.A = P1; scn.ld = U_pad; scn.nb = nbu; scn.prev = 0; scn.skip_first = 0; scn.dep = rA; scn.dep_mult = (unsigned)ncA;
-            B.seg[0] = scn; B.W = Ly.WB.as<float>(); B.ldw = U_pad;
+            scn.A = P1; scn.ld = U_pad; scn.nb = nbu; scn.prev = 0; scn.skip_first = 0; scn.dep = rA; scn.dep_mult = (unsigned)ncA; scn.wb0 = 0;
+            B.seg[0] = scn; B.W = Ly.WBs.as<float>(); B.ldw = U_pad;
             B.bias_first = Ly.bB_first.as<float>(); B.bias_rest = Ly.bB_first.as<float>();
             B.E0 = P1; B.E1 = P2; B.O0 = H; B.epi = REC_PEEP_B;
         }
     }
     HIP_TRY(hipMemcpyAsync(pl.d_roles.p, roles.data(), sizeof(RecStreamRole) * roles.size(), hipMemcpyHostToDevice, e->stream));   // (pageable source: staged before the call returns)
     ra.roles = pl.d_roles.as<RecStreamRole>();
-    ra.n_active = p->d_nact.as<int>(); ra.step_off = p->d_stepoff.as<int>();
+    ra.n_active = p->d_nact.as<int>(); ra.step_off = p->d_stepoff.as<int>(); ra.tile_off = p->d_tileoff.as<int>();
     ra.counters = p->d_sync.as<unsigned>(); ra.abort_flag = p->d_sync.as<int>() + 63;
     HIP_TRY(hipMemsetAsync(p->d_sync.p, 0, sizeof(unsigned) * 63, e->stream));
+    static const bool want_stamps = env_int("AM_LSTM_STAMPS", 0) != 0;
+    ra.stamps = nullptr;
+    if (want_stamps && mi == 0) {   // diagnostic timeline: one row of stamps per role (am_lstm_stamps)
+        const size_t bytes = sizeof(unsigned long long) * (8 * (size_t)ra.n_roles * ra.T + 64 * (size_t)ra.n_roles);   // + one step's batch loop, AM_REC_DBG >> 8
+        AM_TRY(p->d_stamps.ensure(bytes));
+        HIP_TRY(hipMemsetAsync(p->d_stamps.p, 0, bytes, e->stream));
+        ra.stamps = p->d_stamps.as<unsigned long long>();
+        p->stamps_groups = ra.n_roles; p->stamps_T = ra.T;
+    }
     PersistGate& G = gate_of(e);   // one persistent launch at a time per device: every workgroup must be resident
     std::lock_guard<std::mutex> lk(G.mu);
     if (G.last && G.owner != e) HIP_TRY(hipStreamWaitEvent(e->stream, G.last, 0));
@@ -2143,7 +2232,9 @@ extern "C" int am_lstm_stamps(am_pipeline* p, unsigned long long* out, int64_t c
     if (capacity < need) return fail(AM_EINVAL, "am_lstm_stamps: buffer too small");
     HIP_TRY(hipSetDevice(p->e->device));
     AM_TRY(sync_all(p->e));
-    HIP_TRY(hipMemcpy(out, p->d_stamps.p, sizeof(unsigned long long) * need, hipMemcpyDeviceToHost));
+    // (a caller that offers more room also gets what the launch wrote behind the table: the persistent cell kernel's trace of one step's batch loop)
+    const int64_t have = (int64_t)(p->d_stamps.cap / sizeof(unsigned long long));
+    HIP_TRY(hipMemcpy(out, p->d_stamps.p, sizeof(unsigned long long) * std::min(capacity, have), hipMemcpyDeviceToHost));
     return AM_OK;
 }
 

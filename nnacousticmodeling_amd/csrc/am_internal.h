@@ -203,7 +203,8 @@ enum RecEpilogue {
     REC_GRU_A = 1,   // 2 gates (r, z):    Z = sig(z), RH = sig(r)*h_prev                             (phase A of a cell with reset gate)
     REC_GRU_B = 2,   // 1 gate  (h~):      h = Z*act(h~) + (1-Z)*h_prev   with h~ over [x | RH]       (phase B)
     REC_PEEP_A = 3,  // 4 gates (a,i,f,o): c' = tanh(a)*sig(i) + sig(f)*c ; O = o   over [x | h | c]   (phase A of StatefulPeepholeLSTM)
-    REC_PEEP_B = 4   // 1 gate  (peep_o):  h = sig(O + peep_o c') * tanh(c')                          (phase B)
+    REC_PEEP_B = 4,  // 1 gate  (peep_o):  h = sig(O + peep_o c') * tanh(c')                          (phase B)
+    REC_XPART = 5    // no gates: the accumulators of the input part of a phase's product, stored as they are (rec_stream_kernel only)
 };
 struct RecLayerStep {
     const float* A[3]; int K[3];   // K segments of the concatenated operand, each [>= 16-row tiles, K[s]] rows (ld = K[s]); K multiples of 64
@@ -230,24 +231,35 @@ struct RecStreamSeg {
     int prev;                    // 1: rows of step t - 1; 0: rows of step t
     int skip_first;              // 1: the segment does not exist at t == 0 (the state Linears of a cell without a previous state)
     int dep; unsigned dep_mult;  // the role (counter index) that produces those rows in this launch, and its arrivals per step; -1: the plane was complete before the launch
+    int wb0;                     // the segment's first 128-k batch in the role's weights
 };
 struct RecStreamRole {
     RecStreamSeg seg[3];
-    const float* W; int ldw;                       // packed weights [G U_pad, ldw]
+    const float* W; int ldw;                       // packed weights [G U_pad, ldw] in stream order (rec_stream_pack_weights)
     const float* bias_first; const float* bias_rest;
     const float* E0; const float* E1;              // element-wise inputs, time-major planes [rows, U_pad] (rec_cell_math); E0 of MGRU / GRU / PEEP_A: rows of step t - 1
     float* O0; float* O1;                          // element-wise outputs
     int edep; unsigned edep_mult;                  // role whose step-t output the epilogue reads when no tile wait covers it (GRU B at t == 0: Z); -1: none
     int epi, n_col, wg0, counter;                  // RecEpilogue; 64-column workgroups of the role; first workgroup (within a group); counter index
+    // A phase split over two roles: the input part (x W_x^T, epi = REC_XPART, no dependency on the recurrence: it runs ahead) leaves its accumulators
+    // -- per K half, in fragment order -- in `xplane`; the state part starts its accumulators from them, so the sums are folded in the same order
+    // as by one role over both segments.  [tile_off[t] + tile][n_col][8 waves][64 lanes][4] floats.
+    float* xplane;                                 // REC_XPART: where the accumulators go
+    const float* init; int idep; unsigned idep_mult;   // state part: the plane its accumulators start from (nullptr: zeros), the role that writes it
 };
 struct RecStreamArgs {
     const RecStreamRole* roles;                    // device [n_roles]
     int n_roles, NG, wgs_per_group, T, U_pad, U_real, act, max_wgs;
     const int* n_active; const int* step_off;      // device [T], [T + 1]
+    const int* tile_off;                           // device [T]: 16-row tiles of the steps before t (the split phases' accumulator planes)
     unsigned* counters;                            // device [n_roles][NG], zero before the launch
     int* abort_flag;
+    int dbg;                                       // measurement switches (AM_REC_DBG): 1 = every wait polls, 2 = groups in workgroup-id order; with stamps:
+                                                   // 128 = lane 0's accumulator quads of the split phases instead of the poll times, >> 8 = the step whose batch loop is traced
+    unsigned long long* stamps;                    // diagnostic timeline [n_roles][T][8] of 100 MHz ticks, or nullptr (the normal case)
 };
 int rec_stream_resident_wgs(int n_cus);
+void rec_stream_pack_weights(const float* w, int rows, int ld, float* out);   // host: row-major [rows, ld] -> the kernel's stream order
 hipError_t launch_rec_stream(hipStream_t s, const RecStreamArgs& a);
 
 struct ViterbiArgs {

@@ -118,15 +118,25 @@ def test_persistent_cell_form_equals_the_per_tick_kernels(engine, real_ft_path, 
     off = orc.make_offsets(rng, n_utts, n, lo=3, hi=140)
     x = rng.standard_normal((n, 40)).astype(np.float32)
     p = _pipe(engine, network, layers, params, ft)
-    monkeypatch.setenv("AM_REC_STREAM", "2")          # (read once per process by the library: see below)
+    monkeypatch.setenv("AM_REC_STREAM", "2")          # the persistent form whenever it fits (read at every upload; the default is the per-tick kernels)
+    monkeypatch.setenv("AM_REC_SPLIT", "0")           # every phase one role over [input | state]
     whole = p.forward_lstm(x, off, timedelay=2)
     form = p.recurrent_form()
     p.lstm_run()
     assert np.array_equal(p.lstm_download(), whole)   # idempotent: counters re-armed per launch, planes written once per launch
+    monkeypatch.setenv("AM_REC_SPLIT", "2")           # upper layers: input part and state part of a phase as two roles, the accumulators handed over
+    halves = p.forward_lstm(x, off, timedelay=2)
+    assert p.recurrent_form() == (1, 1)
+    assert np.array_equal(halves, whole)
+    p.lstm_run()
+    assert np.array_equal(p.lstm_download(), whole)
+    monkeypatch.delenv("AM_REC_SPLIT")
     monkeypatch.setenv("AM_LSTM_PERSIST", "0")        # every persistent form off (read at upload): the per-tick kernels
     ticks = p.forward_lstm(x, off, timedelay=2)
     monkeypatch.delenv("AM_LSTM_PERSIST")
     assert p.recurrent_form() == (0, 1)
+    monkeypatch.delenv("AM_REC_STREAM")
+    assert np.array_equal(p.forward_lstm(x, off, timedelay=2), whole) and p.recurrent_form() == (0, 1)   # the default: per-tick
     assert form == (1, 1), form
     assert np.array_equal(ticks, whole)
     k = min(n_utts, 5)
