@@ -100,6 +100,7 @@ struct Layer {
     int in = 0, out = 0, in_pad = 0, out_pad = 0;
     int U = 0, U_pad = 0;  // LSTM layers only
     DevBuf W, b, Wlat;
+    DevBuf Ws, Wlats;      // LSTM layers of 768 / 1024 units: W (layers >= 1) and Wlat in the order lstm_stream_kernel streams them (rec_stream_pack_weights)
     // split-f16 precision mode (feed-forward only), built on first use
     float wmax = 0.f;      // max |W| (host scan at creation)
     float w_scale = 1.f;   // exact power of two applied to W before splitting
@@ -595,6 +596,10 @@ extern "C" int am_model_create(am_engine* e, int kind, int n_layers, int activat
             if ((rc = upload(e, Ly.W, w)) != AM_OK) break;
             if ((rc = upload(e, Ly.b, bb)) != AM_OK) break;
             if ((rc = upload(e, Ly.Wlat, wl)) != AM_OK) break;
+            if (Ly.U_pad == 768 || Ly.U_pad == 1024) {   // the widths lstm_stream_kernel takes
+                if (Ly.in_pad == Ly.U_pad && (rc = upload_stream_order(e, Ly.Ws, w, Ly.out_pad, Ly.in_pad)) != AM_OK) break;
+                if ((rc = upload_stream_order(e, Ly.Wlats, wl, Ly.out_pad, Ly.U_pad)) != AM_OK) break;
+            }
             m->max_width = std::max(m->max_width, Ly.U_pad);
         } else {
             Ly.out_pad = gemm_n_pad(Ly.out);
@@ -618,7 +623,7 @@ extern "C" int am_model_destroy(am_model* m)
     if (!m) return AM_OK;
     (void)hipSetDevice(m->e->device);
     for (auto& l : m->L) {
-        l.W.release(); l.b.release(); l.Wlat.release(); l.Whi.release(); l.Wlo.release(); l.b_s.release();
+        l.W.release(); l.b.release(); l.Wlat.release(); l.Ws.release(); l.Wlats.release(); l.Whi.release(); l.Wlo.release(); l.b_s.release();
         l.WA.release(); l.WB.release(); l.WAs.release(); l.WBs.release(); l.bA_first.release(); l.bA_rest.release(); l.bB_first.release(); l.bB_rest.release();
     }
     am_engine* e = m->e;
@@ -1666,6 +1671,9 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
                 const int swgs = stream_ok ? lstm_stream_resident_wgs(U_pad, e->n_cus) : 0;
                 const int lmax = lstm_stream_layers(U_pad, swgs);
                 if (lmax < 1) continue;
+                bool packed = true;   // (the model holds its weights in the kernel's stream order: am_model_create)
+                for (int l = 0; l < m->n_layers; ++l) packed = packed && m->L[l].Wlats.p && (l == 0 || m->L[l].Ws.p);
+                if (!packed) continue;
                 for (int l0 = 0; l0 < m->n_layers; l0 += lmax) {
                     LstmPersistArgs pa{};
                     pa.n_layers = std::min(lmax, m->n_layers - l0); pa.U_pad = U_pad; pa.T = (int)T; pa.slot_base = 0; pa.slot_cap = n_utts;
@@ -2069,7 +2077,7 @@ static int lstm_enqueue(am_pipeline* p)
                     Layer& Ly = m->L[l];
                     LstmPersistLayer& s = pa.L[l - lbase];
                     s.G = l == 0 ? p->d_G.as<float>() : nullptr;
-                    s.bias = Ly.b.as<float>(); s.Wup = l == 0 ? nullptr : Ly.W.as<float>(); s.Wlat = Ly.Wlat.as<float>();
+                    s.bias = Ly.b.as<float>(); s.Wup = l == 0 ? nullptr : Ly.Ws.as<float>(); s.Wlat = Ly.Wlats.as<float>();   // (stream order)
                     s.Hin = l == 0 ? nullptr : Hall + (l - 1) * h_stride;
                     s.H = Hall + l * h_stride; s.Cst = Cplanes + l * h_stride;
                 }

@@ -119,8 +119,11 @@ __device__ __forceinline__ bool stream_pass(const LstmPersistArgs& a, const Lstm
         }
         const float* up0 = NBU ? Ly.Hin + (size_t)r_t * U_pad : nullptr;
         const float* lat0 = Ly.H + (size_t)r_p * U_pad;
-        // this wave's weight fragments of a batch: its gate's 16 columns x its K half (64 k) = 4 x 16 B per lane
-        const size_t wrow = (size_t)(ut * 64 + gate * 16 + l15) * U_pad + kh * (LSTM_KB / 2) + 4 * lq;
+        // this wave's weight fragments of a batch: its gate's 16 columns x its K half (64 k) = 4 x 16 B per lane.  The weights come in STREAM ORDER
+        // (rec_stream_pack_weights: [unit tile][batch][wave][sub-step][lane][4]): a load instruction reads 1 KB of consecutive memory.  From the
+        // row-major matrix it touched 16 rows x 64 B -- 64 line look-ups in the vector cache per instruction, 2048 per stage and workgroup, which is
+        // what bounded a thin step's weight stream (am_cells_stream.hip, rs_load_w).
+        const size_t wlane = (size_t)wave * 1024 + 4 * lane;
         f32x4 wv[NBUF][LSTM_KS];
         auto issue_piece = [&](int b, int e) {   // one 1-KB piece (two rows) of activation tile b
             const float* src = (b < NBU ? up0 + b * LSTM_KB : lat0 + (b - NBU) * LSTM_KB);
@@ -128,9 +131,9 @@ __device__ __forceinline__ bool stream_pass(const LstmPersistArgs& a, const Lstm
             __builtin_amdgcn_global_load_lds(AM_GLOBAL_PTR(src + doff[e]), AM_LDS_PTR(buf + (wave + 8 * e) * 256), 16, 0, 16 /* sc1 */);
         };
         auto issue_weights = [&](int b) {
-            const float* wp = (b < NBU ? Ly.Wup + wrow + b * LSTM_KB : Ly.Wlat + wrow + (b - NBU) * LSTM_KB);
+            const float* wp = (b < NBU ? Ly.Wup + (size_t)(ut * NBU + b) * 8192 : Ly.Wlat + (size_t)(ut * NBL + (b - NBU)) * 8192) + wlane;
 #pragma unroll
-            for (int s = 0; s < LSTM_KS; ++s) wv[b % NBUF][s] = *(const f32x4*)(wp + 16 * s);
+            for (int s = 0; s < LSTM_KS; ++s) wv[b % NBUF][s] = *(const f32x4*)(wp + 256 * s);
         };
         auto issue = [&](int b) {
 #pragma unroll
