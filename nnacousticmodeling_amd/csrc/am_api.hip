@@ -1860,7 +1860,7 @@ static int rec_stack(am_pipeline* p, am_model* m, size_t h_stride)
                 if (m->cell == AM_CELL_MGRU) {
                     epi = REC_MGRU;
                     s.A[1] = hprev; s.K[1] = first ? 0 : U_pad;
-                    s.W = Ly.WA.as<float>(); s.ldw = Ly.Kx + U_pad;
+                    s.W = Ly.WA.as<float>(); s.Ws = Ly.WAs.as<float>(); s.ldw = Ly.Kx + U_pad;
                     s.bias = (first ? Ly.bA_first : Ly.bA_rest).as<float>();
                     s.E0 = hprev; s.O0 = hout;
                 } else if (m->cell == AM_CELL_GRU) {
@@ -1869,12 +1869,12 @@ static int rec_stack(am_pipeline* p, am_model* m, size_t h_stride)
                     if (ph == 0) {
                         epi = REC_GRU_A;
                         s.A[1] = hprev; s.K[1] = first ? 0 : U_pad;
-                        s.W = Ly.WA.as<float>(); s.bias = (first ? Ly.bA_first : Ly.bA_rest).as<float>();
+                        s.W = Ly.WA.as<float>(); s.Ws = Ly.WAs.as<float>(); s.bias = (first ? Ly.bA_first : Ly.bA_rest).as<float>();
                         s.E0 = hprev; s.O0 = Z; s.O1 = RH;
                     } else {
                         epi = REC_GRU_B;
                         s.A[1] = RH; s.K[1] = first ? 0 : U_pad;
-                        s.W = Ly.WB.as<float>(); s.bias = (first ? Ly.bB_first : Ly.bB_rest).as<float>();
+                        s.W = Ly.WB.as<float>(); s.Ws = Ly.WBs.as<float>(); s.bias = (first ? Ly.bB_first : Ly.bB_rest).as<float>();
                         s.E0 = hprev; s.E1 = Z; s.O0 = hout;
                     }
                 } else {   // AM_CELL_PEEPHOLE: c ping-pongs between two planes by time parity (other blocks read c[t-1] as a K segment)
@@ -1883,12 +1883,12 @@ static int rec_stack(am_pipeline* p, am_model* m, size_t h_stride)
                         epi = REC_PEEP_A;
                         s.A[1] = hprev; s.K[1] = first ? 0 : U_pad;
                         s.A[2] = Cprev; s.K[2] = first ? 0 : U_pad;
-                        s.W = Ly.WA.as<float>(); s.ldw = Ly.Kx + 2 * U_pad; s.bias = Ly.bA_first.as<float>();
+                        s.W = Ly.WA.as<float>(); s.Ws = Ly.WAs.as<float>(); s.ldw = Ly.Kx + 2 * U_pad; s.bias = Ly.bA_first.as<float>();
                         s.E0 = Cprev; s.O0 = Cnext; s.O1 = Opre;
                     } else {
                         epi = REC_PEEP_B;
                         s.A[0] = Cnext; s.K[0] = U_pad;
-                        s.W = Ly.WB.as<float>(); s.ldw = U_pad; s.bias = Ly.bB_first.as<float>();
+                        s.W = Ly.WB.as<float>(); s.Ws = Ly.WBs.as<float>(); s.ldw = U_pad; s.bias = Ly.bB_first.as<float>();
                         s.E0 = Cnext; s.E1 = Opre; s.O0 = hout;
                     }
                 }

@@ -180,13 +180,15 @@ __device__ __forceinline__ void rec_wide_body(const RecLayerStep& Ls, int U_pad,
                 dst[e] = *(const f32x4*)(ap + (size_t)r * K + 4 * c4);
             }
         };
-        const float* wbase = Ls.W + (size_t)(bt * 64 + cg * 16 + l15) * Ls.ldw + kh * (LSTM_KB / 2) + 4 * lq;
+        // the weights in stream order ([column block][batch][wave][sub-step][lane][4], rec_stream_pack_weights): a load instruction reads 1 KB of
+        // consecutive memory -- from the row-major matrix it touched 16 rows x 64 B, 64 line look-ups in the vector cache (am_cells_stream.hip, rs_load_w)
+        const float* wbase = Ls.Ws + ((size_t)bt * (Ls.ldw / LSTM_KB) * 8 + wave) * 1024 + 4 * lane;
         auto load_w = [&](int b, f32x4 (&dst)[LSTM_KS]) {
             const bool real = b < nb;
-            const float* wp = wbase + (size_t)(real ? b : nb - 1) * LSTM_KB;
+            const float* wp = wbase + (size_t)(real ? b : nb - 1) * 8192;
 #pragma unroll
             for (int s = 0; s < LSTM_KS; ++s) {
-                const f32x4 v = *(const f32x4*)(wp + 16 * s);
+                const f32x4 v = *(const f32x4*)(wp + 256 * s);
                 // without ZW the only batches past the end are the refills behind the last rotation: loaded, never multiplied
                 dst[s] = (!ZW || real) ? v : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             }
@@ -391,7 +393,7 @@ hipError_t launch_rec_step(hipStream_t s, int epilogue, const RecStepArgs& a)
     if (max_tiles == 0) return hipSuccess;
     bool wide = rec_wide_mode() != 0 && max_tiles > 2;      // <= 32 rows: the K-split form above is the faster one
     for (int l = 0; l < a.n; ++l)
-        if (a.L[l].K[0] % LSTM_KB || a.L[l].K[1] % LSTM_KB || a.L[l].K[2] % LSTM_KB || a.L[l].ldw % 4) wide = false;
+        if (a.L[l].K[0] % LSTM_KB || a.L[l].K[1] % LSTM_KB || a.L[l].K[2] % LSTM_KB || a.L[l].ldw % LSTM_KB || !a.L[l].Ws) wide = false;
     if (wide) {
         switch (epilogue) {
         case REC_MGRU: return rec_wide_launch<2, REC_MGRU>(s, a);

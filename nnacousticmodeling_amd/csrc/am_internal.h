@@ -209,6 +209,7 @@ enum RecEpilogue {
 struct RecLayerStep {
     const float* A[3]; int K[3];   // K segments of the concatenated operand, each [>= 16-row tiles, K[s]] rows (ld = K[s]); K multiples of 64
     const float* W; int ldw;       // packed weights [G*U_pad, ldw]: row = 16*tile + gate*(16/G) + unit-in-tile, columns = the segments in order
+    const float* Ws;               // the same weights in stream order (rec_stream_pack_weights): what rec_wide_kernel reads
     const float* bias;             // [G*U_pad] in the same row order
     const float* E0; const float* E1;  // element-wise inputs  [slots, U_pad] (see RecEpilogue)
     float* O0; float* O1;              // element-wise outputs [slots, U_pad]

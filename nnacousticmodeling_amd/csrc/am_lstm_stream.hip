@@ -82,9 +82,9 @@ __device__ __forceinline__ bool stream_pass(const LstmPersistArgs& a, const Lstm
 {
     constexpr int NBT = NBU + NBL;
     constexpr int ROWS = NT * 16;
-    // tile ring: 3 x 96 rows (5-6 tiles) or 4 x 64 rows.  (Measured for 1-2 tiles: 8 x 32 rows, seven stages ahead instead of three, changes
-    // nothing -- 23.5 against 22.7 us per thin step: such a step moves 512 KB of weights per CU, 134 MB chip-wide, in ~21 us = 6.4 TB/s: it is
-    // bound by the rate at which the chip streams from the Infinity Cache / HBM, not by latency.)
+    // tile ring: 3 x 96 rows (5-6 tiles) or 4 x 64 rows.  (Measured for 1-2 tiles: 8 x 32 rows, seven stages ahead instead of three, does not help --
+    // with row-major weights 23.5 against 22.7 us per thin step, with the weights in stream order 20.2 against 18.2: such a step moves 512 KB of
+    // weights per CU, 134 MB chip-wide, now at 8.7 TB/s out of the Infinity Cache; what is left is the per-batch chain, not latency.)
     constexpr int BUF_ROWS = NT <= 4 ? 64 : 96;
     constexpr int NBUF = NT <= 4 ? 4 : 3;
     constexpr int LEAD = NBUF - 1;
