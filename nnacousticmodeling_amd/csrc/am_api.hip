@@ -1607,7 +1607,7 @@ extern "C" int am_lstm_upload(am_pipeline* p, const float* x, const float* ivec,
             am_model* m = p->members[mi];
             if (m->cell != AM_CELL_LSTM) {
                 // GRU / MGRU / peephole stacks: the per-tick phase kernels, unless AM_REC_STREAM asks for the persistent form (rec_stream_kernel): measured
-                // on the 3 x 512 recipes it is 5-15 % SLOWER than they are (GRU 22.5 against 19.8 ms, MGRU 11.7 / 11.2, peephole 32.9 / 28.6),
+                // on the 3 x 512 recipes it is 17-32 % SLOWER than they are (MGRU 11.7 against 10.0 ms, GRU 22.5 / 17.5, peephole 32.9 / 24.9),
                 // so it is there to be measured, not used.  1 = when its row groups fill the chip -- at least two groups, or a file of at most four row
                 // tiles (1024-unit stacks: one group of 192 workgroups would take every row in three passes) --, 2 = whenever it fits.
                 const int64_t rs_mode = env_int("AM_REC_STREAM", 0);   // (read at every upload, like AM_LSTM_PERSIST)
