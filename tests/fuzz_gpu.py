@@ -172,7 +172,13 @@ def one(eng, rng, ft_full, it):
         p.set_frontend(D, [0], add, scale, 0)
         p.set_members([Model(eng, kind, layers, params)])
         p.set_prior(prior)
+        if kind != "lstm":   # the cells' forms (both switches are read at every upload): per-tick kernels, or one persistent launch with whole / split phases
+            form = int(rng.integers(0, 3))
+            os.environ["AM_REC_STREAM"] = "2" if form else "0"
+            os.environ["AM_REC_SPLIT"] = "2" if form == 2 else "0"
+            desc.update(cell_form=["per-tick", "persistent", "persistent, split phases"][form])
         got = p.forward_lstm(x, offsets, timedelay=td)
+        os.environ.pop("AM_REC_STREAM", None); os.environ.pop("AM_REC_SPLIT", None)
     if got.size and not np.isfinite(want).all():
         # poisoned input (below): the non-finite classes must agree element by element, the finite rows within the tolerance
         same = (np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.isposinf(got), np.isposinf(want)) and np.array_equal(np.isneginf(got), np.isneginf(want)))
