@@ -64,6 +64,9 @@ __global__ __launch_bounds__(512) void rec_step_kernel(const RecStepArgs args)
     const int nc = Ktot >> 6;                               // 64-k chains
     const int m = (nc + 7) >> 3;                            // chains per wave: wave w owns [w*m, (w+1)*m)
     const float* wrow = Ls.W + (size_t)(tile * 16 + l15) * Ls.ldw + 4 * lq;
+    // the same fragments out of the stream-ordered copy (rec_stream_pack_weights: a 64-k chain of a 16-column tile is the fragment of (64-column block
+    // tile / 4, column group tile % 4, 128-k batch chain / 2, K half chain % 2)): 1 KB of consecutive memory per load instruction, not 16 rows x 64 B
+    const float* wso = Ls.Ws ? Ls.Ws + ((size_t)(tile >> 2) * (Ls.ldw / LSTM_KB) * 8 + (tile & 3)) * 1024 + 4 * lane : nullptr;
     for (int c0 = 0; c0 < m; c0 += 2) {                     // two chains = 8 sub-steps of 16 k per round trip
         const int ch0 = w * m + c0;
         const int nch = (ch0 >= nc) ? 0 : ((c0 + 1 < m && ch0 + 1 < nc) ? 2 : 1);
@@ -76,7 +79,8 @@ __global__ __launch_bounds__(512) void rec_step_kernel(const RecStepArgs args)
                 if (k0 < K0) { ld = K0; ap = Ls.A[0] + k0; }
                 else if (k0 < K01) { ld = Ls.K[1]; ap = Ls.A[1] + (k0 - K0); }
                 else { ld = Ls.K[2]; ap = Ls.A[2] + (k0 - K01); }
-                wv[s] = *(const f32x4*)(wrow + k0);
+                const int ch = ch0 + (s >> 2);
+                wv[s] = wso ? *(const f32x4*)(wso + ((size_t)(ch >> 1) * 8 + (ch & 1) * 4) * 1024 + (s & 3) * 256) : *(const f32x4*)(wrow + k0);
 #pragma unroll
                 for (int r = 0; r < R; ++r)
                     if (r < ntile) av[r][s] = *(const f32x4*)(ap + (size_t)(row0 + r * 16 + l15) * ld + 4 * lq);
