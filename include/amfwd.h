@@ -50,6 +50,13 @@ int am_device_count(void);            /* number of visible HIP devices, 0 if non
  * evaluate.py's --gpu names a card by index only) can tell.  buflen >= 16.  No engine needed. */
 int am_device_pci_bus_id(int device, char* buf, int buflen);
 const char* am_last_error(void);      /* thread-local, never NULL                                   */
+/* Host-only helper, exposed so that the layout can be pinned by a test without a GPU: the order in which the kernels that stream weight
+ * fragments every step (rec_wide_kernel, lstm_stream_kernel, rec_stream_kernel) read a packed recurrent weight matrix w[rows, ld]
+ * (rows a multiple of 64 = 4 MFMA column tiles, ld a multiple of 128 = one k batch): out[((((rows/64 block)*ld/128 + batch)*8 + wave)*4 + sub-step)*64 + lane][4]
+ * = w[block*64 + (wave&3)*16 + (lane&15)][batch*128 + (wave>>2)*64 + sub-step*16 + (lane>>4)*4 ..+4] -- the fragment of one wave's
+ * v_mfma_f32_16x16x4_f32 B operand, so that one load instruction covers 1 KB of consecutive memory.  No reference counterpart (Chainer keeps
+ * chainer.links.Linear.W as [out, in], chainer_networks.py:33-52; this is a device-side copy).  Returns AM_EINVAL on a shape it does not take. */
+int am_pack_stream_order(const float* w, int rows, int ld, float* out);
 const char* am_version(void);
 
 /* ---- engine --------------------------------------------------------------------------------------- */

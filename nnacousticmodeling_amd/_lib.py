@@ -28,6 +28,7 @@ c_void_pp = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "am_device_count": (C.c_int, []),
     "am_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "am_pack_stream_order": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "am_last_error": (C.c_char_p, []),
     "am_version": (C.c_char_p, []),
     "am_engine_create": (C.c_int, [C.c_int, c_void_pp]),

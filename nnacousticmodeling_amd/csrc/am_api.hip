@@ -444,6 +444,13 @@ extern "C" int am_decode_elapsed_ms(am_engine* e, float* ms)
     return AM_OK;
 }
 
+extern "C" int am_pack_stream_order(const float* w, int rows, int ld, float* out)
+{
+    if (!w || !out || rows <= 0 || ld <= 0 || rows % 64 || ld % LSTM_KB) return fail(AM_EINVAL, "am_pack_stream_order: rows must be a multiple of 64 and ld of %d", LSTM_KB);
+    rec_stream_pack_weights(w, rows, ld, out);
+    return AM_OK;
+}
+
 extern "C" int am_device_pci_bus_id(int device, char* buf, int buflen)
 {
     if (!buf || buflen < 16) return fail(AM_EINVAL, "am_device_pci_bus_id: the buffer must hold at least 16 bytes");

@@ -72,3 +72,25 @@ def test_product_package_imports_no_torch():
         if name.endswith(".py"):
             src = open(os.path.join(pkg, name)).read()
             assert not re.search(r"^\s*(import|from)\s+(torch|chainer|triton)\b", src, re.M), name
+
+
+def test_stream_order_of_the_recurrent_weights():
+    """The second copy of the cells' / wide LSTMs' packed weights (round 4): element by element the fragment map the kernels assume --
+    out[block][batch][wave][sub-step][lane][j] = w[64 block + 16 (wave & 3) + (lane & 15)][128 batch + 64 (wave >> 2) + 16 sub-step + 4 (lane >> 4) + j]
+    -- a permutation (nothing lost, nothing twice), and the shapes it refuses.  Host code only: no GPU."""
+    import ctypes as C
+    import numpy as np
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    for rows, ld in ((64, 128), (256, 384), (128, 1024)):
+        w = rng.standard_normal((rows, ld)).astype(np.float32)
+        out = np.zeros(rows * ld, np.float32)
+        assert lib.am_pack_stream_order(w.ctypes.data_as(C.POINTER(C.c_float)), rows, ld, out.ctypes.data_as(C.POINTER(C.c_float))) == 0
+        o = out.reshape(rows // 64, ld // 128, 8, 4, 64, 4)
+        blk, bat, wave, sub, lane, j = np.meshgrid(*[np.arange(n) for n in o.shape], indexing="ij")
+        want = w[64 * blk + 16 * (wave & 3) + (lane & 15), 128 * bat + 64 * (wave >> 2) + 16 * sub + 4 * (lane >> 4) + j]
+        assert np.array_equal(o, want)
+        assert np.array_equal(np.sort(out), np.sort(w.ravel()))
+    bad = np.zeros((60, 128), np.float32)
+    assert lib.am_pack_stream_order(bad.ctypes.data_as(C.POINTER(C.c_float)), 60, 128, bad.ctypes.data_as(C.POINTER(C.c_float))) != 0
+    assert lib.am_pack_stream_order(bad.ctypes.data_as(C.POINTER(C.c_float)), 64, 96, bad.ctypes.data_as(C.POINTER(C.c_float))) != 0

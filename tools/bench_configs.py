@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--precision", default="f32", choices=["f32", "split_f16"])
     ap.add_argument("--cell", default="", help="with --which cells: comma-separated subset of gru,mgrurelu,mgrurelur,peepholelstm")
+    ap.add_argument("--shape", default="3x512", help="with --which cells: layers x units (4x1024: the other specom2018 recipe shape)")
     args = ap.parse_args()
     rng = np.random.default_rng(SEED)
     golden = os.path.join(ROOT, "tests", "golden")
@@ -166,21 +167,22 @@ def main():
             p.close()
     if args.which in ("all", "cells"):
         # the other recurrent cells of get_nn at the LSTM config's size
+        L, U = (int(v) for v in args.shape.split("x"))
         for net in (args.cell.split(",") if args.cell else ("gru", "mgrurelu", "mgrurelur", "peepholelstm")):
             if net == "peepholelstm":
-                params = orc.make_peephole_params(rng, 40, 512, 3, 1909)
-                fl = 2 * (40 * 2048 + 2 * 512 * 2048 + 3 * 512 * 2048 + 3 * 3 * 512 * 512 + 512 * 1909)
+                params = orc.make_peephole_params(rng, 40, U, L, 1909)
+                fl = 2 * (40 * 4 * U + (L - 1) * U * 4 * U + L * U * 4 * U + L * 3 * U * U + U * 1909)
             else:
                 g = 2 if net == "mgrurelu" else 3
-                params = orc.make_gru_params(rng, 40, 512, 3, 1909, reset_gate=net != "mgrurelu")
-                fl = 2 * (g * (40 * 512 + 2 * 512 * 512 + 3 * 512 * 512) + 512 * 1909)
-            m = Model(eng, net, 3, params)
+                params = orc.make_gru_params(rng, 40, U, L, 1909, reset_gate=net != "mgrurelu")
+                fl = 2 * (g * (40 * U + (L - 1) * U * U + L * U * U) + U * 1909)
+            m = Model(eng, net, L, params)
             p = Pipeline(eng)
             p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
             p.set_members([m])
             p.lstm_upload(x, None, offsets, 0)
             wall, ms, calls = timed(eng, p.lstm_run, args.steps, 3)
-            report("3x512 %s N=57919 192 utts Tmax=%d" % (net, int(np.diff(offsets).max())), N, wall, ms, calls, fl)
+            report("%s %s N=57919 192 utts Tmax=%d" % (args.shape, net, int(np.diff(offsets).max())), N, wall, ms, calls, fl)
             p.close()
     if args.which in ("all", "ens"):
         plist = [orc.make_mlp_params(rng, 440, 1024, 4, 1909) for _ in range(10)]
