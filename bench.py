@@ -491,7 +491,7 @@ def secondary_records(eng, ft, params, layers, x, steps):
                                    "kernel_ms_sum_with_an_event_pair_per_launch": vprof["viterbi"][1], "launches": vprof["viterbi"][0],
                                    "host_array_to_segments_s": host_s, "frames": n57, "utterances": 192, "segments": sum(len(r) for r in res),
                                    "graph": {"phones": 48, "nodes": B_, "triphones": T_, "states": 1909},
-                                   "roofline": {"bound": "hbm", "kernel": "viterbi_fs_fused_kernel (triphone update + node maxima, one launch per frame over all active utterances; the last frames of a run: viterbi_fs_tri_kernel + viterbi_fs_node_kernel)",
+                                   "roofline": {"bound": "hbm", "kernel": "viterbi_fs_stream_kernel (triphone update + node maxima, one launch per frame: a block keeps a triphone block and walks the active utterance slots; AM_VITERBI_LDS=2 selects round 3's viterbi_fs_fused_kernel)",
                                                 "achieved": vit_bytes / (vit_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": vit_bytes / (vit_ms * 1e-3) / 8e12,
                                                 "algorithmic_bytes": vit_bytes,
                                                 "measured": "one HIP event pair around the pass's launch sequence on the engine's compute stream"}}
