@@ -415,24 +415,28 @@ def secondary_records(eng, ft, params, layers, x, steps):
         p.close()
         for m_ in members:
             m_.close()
-    # (vi) row n4: the GRU stack at the recurrent config's size (chainer L.GRU: two dependent products per step)
-    with _Guarded(out, "gru_3x512") as g:
-        rng = np.random.default_rng(SEED + 5)
-        mg = g.own(Model(eng, "gru", 3, make_gru_params(rng, 40, 512, 3, 1909, reset_gate=True)))
-        p = g.own(Pipeline(eng))
-        p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
-        p.set_members([mg])
-        p.lstm_upload(x[:n57], None, off, 0)
-        kg = max(steps // 4, 3)
-        wall, _, prof = timed_runs(eng, p.lstm_run, kg, 2, pipe=p)
-        fl = 2 * (3 * (40 * 512 + 2 * 512 * 512 + 3 * 512 * 512) + 512 * 1909)
-        out["gru_3x512"] = {"value": n57 * kg / wall, "unit": "frames/s", "ms_per_pass": wall * 1e3 / kg, "frames": n57, "utterances": 192,
-                            "roofline": {"bound": "mfma (dependent time steps)", "kernel": "whole pass", "achieved": fl * n57 * kg / wall / 1e12,
-                                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": fl * n57 * kg / wall / 1e12 / PEAK_F32_MFMA_TFLOPS},
-                            "recurrent_form": "%d of %d members as one persistent launch" % p.recurrent_form(),
-                            "kernels_ms_per_pass": {k_: v[1] / kg for k_, v in prof.items()}, "launches_per_pass": {k_: v[0] // kg for k_, v in prof.items()}}
-        p.close()
-        mg.close()
+    # (vi) row n4: the GRU stack at the recurrent config's size (chainer L.GRU: two dependent products per step), and the reference's own MGRU
+    # (MGRU.py:67-85, no reset gate: one product per step).  Per-tick phase kernels, weights in stream order; the persistent form of these cells
+    # (rec_stream_kernel, AM_REC_STREAM) measured slower and is not the default.
+    for key, net, seed_off in (("gru_3x512", "gru", 5), ("mgrurelu_3x512", "mgrurelu", 11)):
+        with _Guarded(out, key) as g:
+            rng = np.random.default_rng(SEED + seed_off)
+            mg = g.own(Model(eng, net, 3, make_gru_params(rng, 40, 512, 3, 1909, reset_gate=net == "gru")))
+            p = g.own(Pipeline(eng))
+            p.set_frontend(40, [0], ftc["addShift"], ftc["rescale"])
+            p.set_members([mg])
+            p.lstm_upload(x[:n57], None, off, 0)
+            kg = max(steps // 4, 3)
+            wall, _, prof = timed_runs(eng, p.lstm_run, kg, 2, pipe=p)
+            gates = 3 if net == "gru" else 2
+            fl = 2 * (gates * (40 * 512 + 2 * 512 * 512 + 3 * 512 * 512) + 512 * 1909)
+            out[key] = {"value": n57 * kg / wall, "unit": "frames/s", "ms_per_pass": wall * 1e3 / kg, "frames": n57, "utterances": 192,
+                        "roofline": {"bound": "mfma (dependent time steps)", "kernel": "whole pass", "achieved": fl * n57 * kg / wall / 1e12,
+                                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": fl * n57 * kg / wall / 1e12 / PEAK_F32_MFMA_TFLOPS},
+                        "recurrent_form": "%d of %d members as one persistent launch" % p.recurrent_form(),
+                        "kernels_ms_per_pass": {k_: v[1] / kg for k_, v in prof.items()}, "launches_per_pass": {k_: v[0] // kg for k_, v in prof.items()}}
+            p.close()
+            mg.close()
     # (vii) row n4: TDNN 5-5-5-5 x 1024 (scripts/papers/tsd2018/run.sh:22-30): every (1, k) convolution as one MFMA GEMM with windowed rows
     with _Guarded(out, "tdnn_5555x1024") as g:
         from nnacousticmodeling_amd.kaldi_ft import tdnn_splice, tile_centre_frame
