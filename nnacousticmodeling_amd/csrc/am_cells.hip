@@ -395,7 +395,9 @@ hipError_t launch_rec_step(hipStream_t s, int epilogue, const RecStepArgs& a)
         nc_max = std::max(nc_max, (L.K[0] + L.K[1] + L.K[2]) / 64);
     }
     if (max_tiles == 0) return hipSuccess;
-    bool wide = rec_wide_mode() != 0 && max_tiles > 2;      // <= 32 rows: the K-split form above is the faster one
+    static const int wide_min = getenv("AM_REC_WIDE_MIN_TILES") ? atoi(getenv("AM_REC_WIDE_MIN_TILES")) : 3;
+    bool wide = rec_wide_mode() != 0 && max_tiles >= wide_min;   // <= 32 rows: the K-split form above is the faster one (re-measured with the weights
+                                                                 // in stream order, 3 x 512 GRU: from 3 tiles 17.1 ms, from 2 tiles 17.3, always 18.4)
     for (int l = 0; l < a.n; ++l)
         if (a.L[l].K[0] % LSTM_KB || a.L[l].K[1] % LSTM_KB || a.L[l].K[2] % LSTM_KB || a.L[l].ldw % LSTM_KB || !a.L[l].Ws) wide = false;
     if (wide) {
